@@ -1,0 +1,182 @@
+/*
+ * include/pixie_hip.h -- C ABI of libpixie_hip.so, the MI355X (gfx950) implementation of
+ * Pixie's material_mode=neural inference hot path.
+ *
+ * The reference (vlongle/pixie) has no FFI/plugin layer for this path: its stages are Python
+ * classes calling torch ops and NVIDIA-Warp kernels in-process.  This
+ * header is therefore the boundary a maintainer would bind from the reference's Python with
+ * ctypes (INTEGRATION.md shows the stubs); each entry point cites the reference call it
+ * replaces.  Paths are relative to the reference root:
+ *   WG = third_party/Wavelet-Generation,  PG = third_party/PhysGaussian.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, scalars.  No torch / HIP types in signatures;
+ *     `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - every pointer named d_* is DEVICE memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); the library never frees it.  Handles own their internal device state.
+ *   - all launches are asynchronous on `stream`; nothing here synchronises the device
+ *     unless documented.
+ *   - return value 0 = success; non-zero = failure, message via pixie_last_error().
+ *   - thread-compatible per handle; pixie_last_error() is thread-local.
+ */
+#ifndef PIXIE_HIP_H
+#define PIXIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pixie_last_error(void);
+/* Library/version probe: returns the gfx arch string the kernels were compiled for. */
+const char* pixie_build_arch(void);
+
+/* ======================================================================================
+ * (B) MLS-MPM solver -- replaces PG/mpm_solver_warp/mpm_solver_warp.py: MPM_Simulator_WARP
+ * ====================================================================================== */
+typedef struct pixie_mpm pixie_mpm;
+
+/* MPM_Simulator_WARP.__init__/initialize (mpm_solver_warp.py:48-180): allocates particle and
+ * grid state for n_particles and an n_grid^3 grid over [0,grid_lim]^3; v=0, C=0, F_trial=I. */
+int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_lim);
+int pixie_mpm_destroy(pixie_mpm* h);
+
+/* Field import/export in the reference's AoS layouts (warp_utils.py:42-74):
+ *   "x","v": float[n][3]; "F","F_trial","C","stress": float[n][9] row-major;
+ *   "vol","mass","density","E","nu","mu","lam","bulk","yield_stress": float[n];
+ *   "material","selection": int32[n]; "init_cov","cov": float[n][6];
+ *   grids (export only): "grid_m": float[ng^3], "grid_v_in","grid_v_out": float[ng^3][3].
+ * Replaces import_particle_*_from_torch / export_particle_*_to_torch
+ * (mpm_solver_warp.py:659-741) and wp.from_torch assignments such as gs_simulation.py:528.
+ * `count` is the number of scalars in the caller's buffer (checked). */
+int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64_t count, void* stream);
+int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t count, void* stream);
+/* set_value_to_{float,int}_array (warp_utils.py:222-230) as used by set_parameters_dict. */
+int pixie_mpm_fill_field(pixie_mpm* h, const char* name, double value, void* stream);
+
+/* Scalars of MPMModelStruct set by set_parameters_dict (mpm_solver_warp.py:386-433):
+ * "rpic_damping","grid_v_damping_scale","hardening","xi","softening","plastic_viscosity",
+ * "friction_angle","gx","gy","gz","time". */
+int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value);
+int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value);
+
+/* get_float_array_product(density, vol, mass) (mpm_solver_warp.py:416-425). */
+int pixie_mpm_update_mass(pixie_mpm* h, void* stream);
+/* finalize_mu_lam / compute_bulk (mpm_solver_warp.py:465-471, 505-511; mpm_utils.py:282-293). */
+int pixie_mpm_finalize_mu_lam(pixie_mpm* h, int with_bulk, void* stream);
+/* apply_additional_params (mpm_utils.py:591-610): box-select E, nu, density, material. */
+int pixie_mpm_apply_additional_params(pixie_mpm* h, const double point[3], const double size[3], double E,
+                                      double nu, double density, int material, void* stream);
+
+/* Grid boundary conditions, applied in registration order after the grid update. */
+enum { PIXIE_BC_SURFACE = 0, PIXIE_BC_CUBOID = 1, PIXIE_BC_BBOX = 2 };
+typedef struct pixie_bc_desc {
+    int32_t type;          /* PIXIE_BC_* */
+    int32_t surface_type;  /* surface collider: 0 sticky, 1 slip, 11 cut, 2 other (mpm_solver_warp.py:770-779) */
+    int32_t reset;         /* cuboid (mpm_solver_warp.py:895-897) */
+    int32_t pad_;
+    double point[3], size[3], velocity[3], normal[3];
+    double start_time, end_time, friction;
+} pixie_bc_desc;
+/* add_surface_collider (:749-843), set_velocity_on_cuboid (:853-908), add_bounding_box (:910-977). */
+int pixie_mpm_add_bc(pixie_mpm* h, const pixie_bc_desc* bc);
+
+/* Pre-P2G particle modifiers; masks are fixed at registration from the current positions. */
+enum { PIXIE_PM_IMPULSE = 0, PIXIE_PM_TRANSLATION = 1, PIXIE_PM_ROTATION = 2 };
+typedef struct pixie_pmod_desc {
+    int32_t type; /* PIXIE_PM_* */
+    int32_t pad_;
+    double point[3], size[3];          /* box selection (mpm_utils.py:613-642) */
+    double force[3];                   /* impulse: v += force/mass*dt (mpm_solver_warp.py:1015-1027) */
+    double velocity[3];                /* translation pin (:1061-1073) */
+    double normal[3], h1[3], h2[3];    /* rotation cylinder axes, prepared as :1092-1117 */
+    double half_height, radius, rotation_scale, translation_scale;
+    double start_time, end_time;
+} pixie_pmod_desc;
+/* add_impulse_on_particles (:982-1029), enforce_particle_velocity_translation (:1031-1075),
+ * enforce_particle_velocity_rotation (:1080-1181). */
+int pixie_mpm_add_particle_modifier(pixie_mpm* h, const pixie_pmod_desc* pm, void* stream);
+
+/* p2g2p (mpm_solver_warp.py:514-637), n_substeps times with the same dt; advances h->time. */
+int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream);
+/* One phase of a substep, for per-kernel parity tests: 0 = pre-P2G modifiers + stress + P2G,
+ * 1 = grid update + damping + BCs (+ host `modify`), 2 = G2P.  Does not advance time. */
+int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream);
+
+/* compute_cov_from_F (mpm_utils.py:529-553) and compute_R_from_F (:556-580) as used by
+ * export_particle_cov_to_torch / export_particle_R_to_torch (mpm_solver_warp.py:702-741). */
+int pixie_mpm_export_cov(pixie_mpm* h, float* d_cov /* [n][6] */, void* stream);
+int pixie_mpm_export_R(pixie_mpm* h, float* d_R /* [n][9] */, void* stream);
+/* Particles whose 3x3x3 stencil left the grid (undefined behaviour in the reference; skipped here).
+ * Synchronises `stream`. */
+int pixie_mpm_out_of_bounds(pixie_mpm* h, int64_t* count, void* stream);
+/* Average duration in ms of the fused particle kernel / grid kernel over the launches since the
+ * last call, measured with HIP events on `stream` (enable with set_scalar "profile"=1). */
+int pixie_mpm_kernel_times(pixie_mpm* h, double* particle_ms, double* grid_ms, int64_t* n_launches);
+
+/* ======================================================================================
+ * (A) 3D U-Net operators -- replace the torch ops under WG/models/module/diffusion_network.py
+ *     (MyUNetModel :712-935, MyResBlock :639-710, FeatureProjector :534-589, AttentionBlock
+ *     :192-242, Upsample/Downsample :51-97).  Activations are NCDHW float32, batch 1.
+ * ====================================================================================== */
+
+/* Prologue applied to every input element before the convolution (i.e. the normalisation +
+ * activation that precede each conv in the reference graph), fused into the tile load:
+ *   t = x * a[c] + b[c]                       (a,b: per-channel, from pixie_norm_finalize)
+ *   t = t * gamma[d,h,w] + beta[d,h,w]        (if d_gamma != NULL: spatial LayerNorm affine)
+ *   t = act(t):  0 none, 1 LeakyReLU(0.02), 2 SiLU
+ * Zero padding applies to the activated tensor, as in the reference. */
+typedef struct pixie_conv_desc {
+    /* input: channel-concatenation of up to two tensors (th.cat([h, skip]), :932) */
+    const float* d_in0; int32_t c0;
+    const float* d_in1; int32_t c1;           /* d_in1 may be NULL (c1 = 0) */
+    int32_t in_d, in_h, in_w;                 /* spatial size of the stored input tensors */
+    int32_t upsample;                         /* 1: nearest x2 before the conv (Upsample :67-72) */
+    int32_t stride;                           /* 1, or 2 (Downsample :89-91) */
+    int32_t ksize;                            /* 3 (padding 1) or 1 (padding 0) */
+    /* prologue */
+    const float* d_pro_a; const float* d_pro_b;   /* [c0+c1] or NULL = identity */
+    const float* d_gamma; const float* d_beta;    /* [D][H][W] of the conv-input grid, or NULL */
+    int32_t act;
+    /* weights, repacked by pixie_conv_pack_weights: [k^3][c_in][c_out_padded] */
+    const float* d_w; const float* d_bias;        /* bias [c_out] or NULL */
+    int32_t c_out;
+    /* epilogue: out = conv + bias (+ residual) */
+    const float* d_residual;                      /* [c_out][OD][OH][OW] or NULL; may alias d_out */
+    float* d_out;                                 /* [c_out][OD][OH][OW] */
+} pixie_conv_desc;
+
+/* Repack an nn.Conv3d / nn.Conv1d weight (c_out, c_in, k,k,k) into the kernel's
+ * [tap][c_in][c_out_padded] layout; c_out_padded = pixie_conv_cout_padded(c_out). */
+int pixie_conv_cout_padded(int c_out);
+int pixie_conv_pack_weights(const float* d_w_oidhw, float* d_w_packed, int c_out, int c_in, int ksize, void* stream);
+/* F.conv3d / nn.Conv3d forward on the fp32 MFMA path. */
+int pixie_conv3d_forward(const pixie_conv_desc* desc, void* stream);
+
+/* Per-channel sum and sum of squares over the spatial extent: d_sums[2*c] (float64). */
+int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream);
+/* Turn channel sums into the prologue's (a,b):
+ *  mode 0: LayerNorm([D,H,W]) statistics per channel (biased var, eps): a = rstd, b = -mean*rstd
+ *          (affine gamma/beta are spatial and applied in the conv prologue);
+ *  mode 1: GroupNorm(groups, channels): a = rstd_g*weight[c], b = bias[c] - mean_g*rstd_g*weight[c]. */
+int pixie_norm_finalize(const double* d_sums, int channels, int64_t spatial, int mode, int groups, double eps,
+                        const float* d_weight, const float* d_bias, float* d_a, float* d_b, void* stream);
+
+/* QKVAttention (diffusion_network.py:218-242), single head: qkv [3C][T] -> out [C][T],
+ * softmax over keys of (q*s)^T(k*s), s = C^-1/4, streamed (no T x T buffer). */
+int pixie_attention_forward(const float* d_qkv, float* d_out, int channels, int tokens, void* stream);
+
+/* y = x*a[c] + b[c] materialised (GroupNorm output feeding a non-conv consumer). */
+int pixie_channel_affine(const float* d_x, const float* d_a, const float* d_b, float* d_y, int channels,
+                         int64_t spatial, void* stream);
+
+/* process_batch/save_predictions (WG/trainer/inference_combined.py:124-126,186-195):
+ * combined[0:3] = cont_pred; combined[3+k] = (argmax_c logits == k), ties -> lowest index. */
+int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial,
+                              float* d_combined, int32_t* d_argmax /* may be NULL */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXIE_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libpixie_hip.so (declared in include/pixie_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, the caller gets an
+exception.  Torch is used only for device memory (tensor.data_ptr()) and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixie_hip.so")
+
+
+class PixieHipError(RuntimeError):
+    pass
+
+
+class BCDesc(C.Structure):
+    """struct pixie_bc_desc"""
+    _fields_ = [("type", C.c_int32), ("surface_type", C.c_int32), ("reset", C.c_int32), ("pad_", C.c_int32),
+                ("point", C.c_double * 3), ("size", C.c_double * 3), ("velocity", C.c_double * 3),
+                ("normal", C.c_double * 3), ("start_time", C.c_double), ("end_time", C.c_double),
+                ("friction", C.c_double)]
+
+
+class PModDesc(C.Structure):
+    """struct pixie_pmod_desc"""
+    _fields_ = [("type", C.c_int32), ("pad_", C.c_int32),
+                ("point", C.c_double * 3), ("size", C.c_double * 3), ("force", C.c_double * 3),
+                ("velocity", C.c_double * 3), ("normal", C.c_double * 3), ("h1", C.c_double * 3),
+                ("h2", C.c_double * 3), ("half_height", C.c_double), ("radius", C.c_double),
+                ("rotation_scale", C.c_double), ("translation_scale", C.c_double),
+                ("start_time", C.c_double), ("end_time", C.c_double)]
+
+
+class ConvDesc(C.Structure):
+    """struct pixie_conv_desc"""
+    _fields_ = [("d_in0", C.c_void_p), ("c0", C.c_int32),
+                ("d_in1", C.c_void_p), ("c1", C.c_int32),
+                ("in_d", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("upsample", C.c_int32), ("stride", C.c_int32), ("ksize", C.c_int32),
+                ("d_pro_a", C.c_void_p), ("d_pro_b", C.c_void_p),
+                ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p),
+                ("act", C.c_int32),
+                ("d_w", C.c_void_p), ("d_bias", C.c_void_p),
+                ("c_out", C.c_int32),
+                ("d_residual", C.c_void_p), ("d_out", C.c_void_p)]
+
+
+# every symbol include/pixie_hip.h declares: name -> (restype, argtypes)
+_VP, _I, _I64, _D, _S = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_char_p
+_D3 = C.POINTER(C.c_double)
+SIGNATURES = {
+    "pixie_last_error": (C.c_char_p, []),
+    "pixie_build_arch": (C.c_char_p, []),
+    "pixie_mpm_create": (_I, [C.POINTER(_VP), _I, _I, _D]),
+    "pixie_mpm_destroy": (_I, [_VP]),
+    "pixie_mpm_set_field": (_I, [_VP, _S, _VP, _I64, _VP]),
+    "pixie_mpm_get_field": (_I, [_VP, _S, _VP, _I64, _VP]),
+    "pixie_mpm_fill_field": (_I, [_VP, _S, _D, _VP]),
+    "pixie_mpm_set_scalar": (_I, [_VP, _S, _D]),
+    "pixie_mpm_get_scalar": (_I, [_VP, _S, C.POINTER(_D)]),
+    "pixie_mpm_update_mass": (_I, [_VP, _VP]),
+    "pixie_mpm_finalize_mu_lam": (_I, [_VP, _I, _VP]),
+    "pixie_mpm_apply_additional_params": (_I, [_VP, _D3, _D3, _D, _D, _D, _I, _VP]),
+    "pixie_mpm_add_bc": (_I, [_VP, C.POINTER(BCDesc)]),
+    "pixie_mpm_add_particle_modifier": (_I, [_VP, C.POINTER(PModDesc), _VP]),
+    "pixie_mpm_step": (_I, [_VP, _D, _I, _VP]),
+    "pixie_mpm_phase": (_I, [_VP, _I, _D, _VP]),
+    "pixie_mpm_export_cov": (_I, [_VP, _VP, _VP]),
+    "pixie_mpm_export_R": (_I, [_VP, _VP, _VP]),
+    "pixie_mpm_out_of_bounds": (_I, [_VP, C.POINTER(_I64), _VP]),
+    "pixie_mpm_kernel_times": (_I, [_VP, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
+    "pixie_conv_cout_padded": (_I, [_I]),
+    "pixie_conv_pack_weights": (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    "pixie_conv3d_forward": (_I, [C.POINTER(ConvDesc), _VP]),
+    "pixie_channel_sums": (_I, [_VP, _I, _I64, _VP, _VP]),
+    "pixie_norm_finalize": (_I, [_VP, _I, _I64, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
+    "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
+    "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
+    "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libpixie_hip.so and type every entry point; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PixieHipError(
+            f"{LIB_PATH} not found: build it with `python -m pixie_amd.build` (hipcc, gfx950). "
+            "pixie_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pixie_last_error()
+        raise PixieHipError(f"{what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream as an integer (0 = default stream)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])

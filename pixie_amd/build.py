@@ -1,0 +1,75 @@
+"""Builds pixie_amd/libpixie_hip.so (gfx950) in-tree with hipcc.
+
+`python -m pixie_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a
+GPU; the resulting .so is git-ignored but travels with the working tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libpixie_hip.so")
+ARCH = "gfx950"
+SOURCES = ["common.hip", "mpm.hip", "unet_ops.hip", "conv3d_mfma.hip"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "pixie_hip.h"))
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and _newer(obj, [sp] + headers):
+            continue
+        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- hipcc failed on {src} ---\n{out}\n")
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed; see messages above")
+    if force or procs or not _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,485 @@
+"""Drop-in for the reference's MPM solver class on MI355X.
+
+Mirrors `MPM_Simulator_WARP` and the module-level helpers of
+third_party/PhysGaussian/mpm_solver_warp/mpm_solver_warp.py (lines cited per method): same
+method names, argument meaning, defaults and error behaviour, so that gs_simulation.py and
+material_field.py can drive it unchanged (INTEGRATION.md lists the two places that passed
+Warp arrays and now pass torch tensors).  All compute is in libpixie_hip.so (csrc/mpm.hip);
+this file only marshals arguments.  There is no CPU path.
+
+Differences a caller can observe, by design:
+  * export_*_to_torch return fresh tensors in the caller's particle order instead of zero-copy
+    aliases of solver memory (the solver keeps particles in its own SoA layout);
+  * `run(dt, n)` / `p2g2p_n` step n substeps in one call (2 launches per substep, no host sync);
+    `p2g2p(step, dt)` is `run(dt, 1)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BCDesc, PModDesc, check, d3
+
+# mpm_solver_warp.py:10-26
+MATERIAL_ID_TO_NAME = {0: "jelly", 1: "metal", 2: "sand", 3: "visplas", 4: "fluid", 5: "snow", 6: "stationary"}
+EXCLUDED_MATERIAL_NAMES = ["visplas", "fluid"]
+NAME_TO_MATERIAL_ID = {name: i for i, name in MATERIAL_ID_TO_NAME.items() if name not in EXCLUDED_MATERIAL_NAMES}
+NAME_TO_MATERIAL_ID.update({"elastic": 0, "rigid": 6})
+
+
+def get_material_name(material_id):
+    """mpm_solver_warp.py:29-39 -- despite its name the reference maps NAME -> id (or -1)."""
+    return NAME_TO_MATERIAL_ID.get(material_id, -1)
+
+
+def get_material_id(material_name):
+    """mpm_solver_warp.py:41-45"""
+    return NAME_TO_MATERIAL_ID.get(material_name, -1)
+
+
+_FLOAT_FIELDS = {"x": 3, "v": 3, "F": 9, "F_trial": 9, "C": 9, "stress": 9, "vol": 1, "mass": 1, "density": 1,
+                 "E": 1, "nu": 1, "mu": 1, "lam": 1, "bulk": 1, "yield_stress": 1, "init_cov": 6, "cov": 6}
+_INT_FIELDS = {"material": 1, "selection": 1}
+_PERSISTENT = ["x", "v", "F", "F_trial", "C", "vol", "mass", "density", "E", "nu", "mu", "lam", "bulk",
+               "yield_stress", "material", "selection", "init_cov"]
+
+
+class _ArrayView:
+    """What `solver.mpm_state.particle_x` returns: supports .numpy() like a Warp array."""
+
+    def __init__(self, solver, name):
+        self._solver, self._name = solver, name
+
+    def torch(self):
+        return self._solver.get_field(self._name)
+
+    def numpy(self):
+        return self.torch().cpu().numpy()
+
+    def __len__(self):
+        return self._solver.n_particles
+
+
+class _StructView:
+    """Attribute proxy standing in for MPMStateStruct / MPMModelStruct (warp_utils.py:6-74)."""
+
+    def __init__(self, solver, prefix, scalars=()):
+        object.__setattr__(self, "_solver", solver)
+        object.__setattr__(self, "_prefix", prefix)
+        object.__setattr__(self, "_scalars", dict(scalars))
+
+    def _field(self, attr):
+        name = attr[len(self._prefix):] if self._prefix and attr.startswith(self._prefix) else attr
+        if name in _FLOAT_FIELDS or name in _INT_FIELDS or name in ("grid_m", "grid_v_in", "grid_v_out"):
+            return name
+        return None
+
+    def __getattr__(self, attr):
+        if attr in self._scalars:
+            return self._scalars[attr]()
+        name = self._field(attr)
+        if name is None:
+            raise AttributeError(attr)
+        return _ArrayView(self._solver, name)
+
+    def __setattr__(self, attr, value):
+        name = self._field(attr)
+        if name is None:
+            self._solver._set_model_scalar(attr, value)
+            return
+        if isinstance(value, _ArrayView):
+            value = value.torch()
+        self._solver.set_field(name, value)
+
+
+class MPM_Simulator_WARP:
+    """mpm_solver_warp.py:47-1210"""
+
+    def __init__(self, n_particles, n_grid=100, grid_lim=1.0, device="cuda:0"):
+        self._h = None
+        self.initialize(n_particles, n_grid, grid_lim, device=device)
+        self.time_profile = {}
+
+    # ------------------------------------------------------------------ lifetime
+    def initialize(self, n_particles, n_grid=100, grid_lim=1.0, device="cuda:0"):
+        """:52-180"""
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.PixieHipError("MPM_Simulator_WARP needs a HIP device; pixie_amd has no CPU fallback")
+        self._release()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.n_particles = int(n_particles)
+        self.n_grid = int(n_grid)
+        self.grid_lim = float(grid_lim)
+        h = C.c_void_p()
+        check(lib.pixie_mpm_create(C.byref(h), self.n_particles, self.n_grid, self.grid_lim), "pixie_mpm_create")
+        self._h = h
+        self._material = 0
+        self._gravity = [0.0, 0.0, 0.0]
+        self.update_cov_with_F = False
+        self.mpm_state = _StructView(self, "particle_")
+        self.mpm_model = _StructView(self, "", scalars={
+            "n_grid": lambda: self.n_grid, "grid_lim": lambda: self.grid_lim,
+            "dx": lambda: self._get_scalar("dx"), "inv_dx": lambda: self._get_scalar("inv_dx"),
+            "material": lambda: self._material, "n_particles": lambda: self.n_particles,
+            "grid_v_damping_scale": lambda: self._get_scalar("grid_v_damping_scale"),
+            "rpic_damping": lambda: self._get_scalar("rpic_damping"),
+            "alpha": lambda: self._get_scalar("alpha"),
+            "gravitational_accelaration": lambda: list(self._gravity),
+            "update_cov_with_F": lambda: False,
+        })
+
+    def _release(self):
+        if getattr(self, "_h", None):
+            _lib.load().pixie_mpm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def _stream(self):
+        return _lib.current_stream_ptr()
+
+    @property
+    def time(self):
+        return self._get_scalar("time")
+
+    @time.setter
+    def time(self, value):
+        check(_lib.load().pixie_mpm_set_scalar(self._h, b"time", float(value)), "set time")
+
+    def _get_scalar(self, key):
+        out = C.c_double(0.0)
+        check(_lib.load().pixie_mpm_get_scalar(self._h, key.encode(), C.byref(out)), f"get_scalar({key})")
+        return out.value
+
+    def _set_scalar(self, key, value):
+        check(_lib.load().pixie_mpm_set_scalar(self._h, key.encode(), float(value)), f"set_scalar({key})")
+
+    def _set_model_scalar(self, attr, value):
+        if attr == "gravitational_accelaration":
+            self._gravity = [float(value[0]), float(value[1]), float(value[2])]
+            for ax, nm in enumerate(("gx", "gy", "gz")):
+                self._set_scalar(nm, self._gravity[ax])
+        elif attr == "material":
+            self._material = int(value)
+        elif attr in ("rpic_damping", "grid_v_damping_scale", "hardening", "xi", "softening", "plastic_viscosity",
+                      "friction_angle"):
+            self._set_scalar(attr, value)
+        else:
+            raise AttributeError(f"cannot set mpm_model.{attr}")
+
+    def _as_device_tensor(self, value, dtype):
+        if isinstance(value, np.ndarray):
+            value = torch.from_numpy(np.ascontiguousarray(value))
+        elif not torch.is_tensor(value):
+            value = torch.as_tensor(value)
+        return value.detach().to(device=self.device, dtype=dtype).contiguous()
+
+    def set_field(self, name, value):
+        dtype = torch.int32 if name in _INT_FIELDS else torch.float32
+        t = self._as_device_tensor(value, dtype)
+        check(_lib.load().pixie_mpm_set_field(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel(), self._stream),
+              f"set_field({name})")
+
+    def get_field(self, name):
+        n, g = self.n_particles, self.n_grid
+        if name in _INT_FIELDS:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+        elif name in _FLOAT_FIELDS:
+            k = _FLOAT_FIELDS[name]
+            out = torch.empty((n, k) if k > 1 else (n,), dtype=torch.float32, device=self.device)
+        elif name == "grid_m":
+            out = torch.empty((g, g, g), dtype=torch.float32, device=self.device)
+        elif name in ("grid_v_in", "grid_v_out"):
+            out = torch.empty((g, g, g, 3), dtype=torch.float32, device=self.device)
+        else:
+            raise KeyError(name)
+        check(_lib.load().pixie_mpm_get_field(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), self._stream),
+              f"get_field({name})")
+        return out
+
+    def _fill(self, name, value):
+        check(_lib.load().pixie_mpm_fill_field(self._h, name.encode(), float(value), self._stream), f"fill({name})")
+
+    def _update_mass(self):
+        check(_lib.load().pixie_mpm_update_mass(self._h, self._stream), "update_mass")
+
+    # ------------------------------------------------------------------ initial data
+    def load_initial_data_from_torch(self, tensor_x, tensor_volume, tensor_cov=None, n_grid=100, grid_lim=1.0,
+                                     device="cuda:0"):
+        """:234-281"""
+        self.dim, n = tensor_x.shape[1], tensor_x.shape[0]
+        assert tensor_x.shape[0] == tensor_volume.shape[0]
+        self.initialize(n, n_grid, grid_lim, device=device)
+        self.import_particle_x_from_torch(tensor_x, device=device)
+        self.set_field("vol", tensor_volume)
+        if tensor_cov is not None:
+            self.set_field("init_cov", tensor_cov.reshape(-1))
+        # v = 0 and F_trial = I are the create() defaults (:262-277)
+        print("Particles initialized from torch data.")
+        print("Total particles: ", self.n_particles)
+
+    def set_parameters(self, device="cuda:0", **kwargs):
+        """:284-285"""
+        self.set_parameters_dict(kwargs, device)
+
+    def set_parameters_dict(self, kwargs={}, device="cuda:0"):
+        """:287-463"""
+        if "material" in kwargs:
+            print("Setting material to ", kwargs["material"])
+            self._material = get_material_name(kwargs["material"])
+            print("Material ID: ", self._material)
+            if self._material == -1:
+                raise TypeError("Undefined material type")
+        new_lim = kwargs.get("grid_lim", self.grid_lim)
+        new_ng = kwargs.get("n_grid", self.n_grid)
+        if float(new_lim) != self.grid_lim or int(new_ng) != self.n_grid:
+            self._regrid(int(new_ng), float(new_lim))
+        self._fill("material", self._material)  # :345-354
+        if "E" in kwargs:
+            self._fill("E", kwargs["E"])
+        if "nu" in kwargs:
+            self._fill("nu", kwargs["nu"])
+        if "bulk_modulus" in kwargs:
+            self._fill("bulk", kwargs["bulk_modulus"])
+        if "yield_stress" in kwargs:
+            self._fill("yield_stress", kwargs["yield_stress"])
+        for key in ("hardening", "xi", "friction_angle"):
+            if key in kwargs:
+                self._set_scalar(key, kwargs[key])
+        if "g" in kwargs:
+            self._set_model_scalar("gravitational_accelaration", kwargs["g"])
+        if "spawn_offset" in kwargs:  # :400-406
+            off = kwargs["spawn_offset"]
+            pos = self.export_particle_x_to_torch()
+            pos[:, 0] += off[0]; pos[:, 1] += off[1]; pos[:, 2] += off[2]
+            self.import_particle_x_from_torch(pos)
+        if "density" in kwargs:
+            self._fill("density", kwargs["density"])
+            self._update_mass()
+        for key in ("rpic_damping", "plastic_viscosity", "softening", "grid_v_damping_scale"):
+            if key in kwargs:
+                self._set_scalar(key, kwargs[key])
+        if "additional_material_params" in kwargs:  # :435-463
+            lib = _lib.load()
+            for params in kwargs["additional_material_params"]:
+                if isinstance(params["material"], str):
+                    params["material"] = get_material_name(params["material"])
+                check(lib.pixie_mpm_apply_additional_params(self._h, d3(params["point"]), d3(params["size"]),
+                                                            float(params["E"]), float(params["nu"]),
+                                                            float(params["density"]), int(params["material"]),
+                                                            self._stream), "apply_additional_params")
+            self._update_mass()
+
+    def _regrid(self, n_grid, grid_lim):
+        """set_parameters_dict may change n_grid / grid_lim after the particles were loaded (:315-342)."""
+        saved = {nm: self.get_field(nm) for nm in _PERSISTENT}
+        t = self.time
+        self.initialize(self.n_particles, n_grid, grid_lim, device=str(self.device))
+        for nm, val in saved.items():
+            self.set_field(nm, val)
+        self.time = t
+
+    def set_per_particle(self, E=None, nu=None, density=None, material=None, yield_stress=None):
+        """Per-particle material assignment -- what material_field.py:343-363 does with N
+        apply_additional_params launches, as plain array uploads."""
+        if E is not None: self.set_field("E", E)
+        if nu is not None: self.set_field("nu", nu)
+        if material is not None: self.set_field("material", material)
+        if yield_stress is not None: self.set_field("yield_stress", yield_stress)
+        if density is not None:
+            self.set_field("density", density)
+            self._update_mass()
+
+    def finalize_mu_lam(self, device="cuda:0"):
+        """:465-471"""
+        check(_lib.load().pixie_mpm_finalize_mu_lam(self._h, 0, self._stream), "finalize_mu_lam")
+
+    def finalize_mu_lam_bulk(self, device="cuda:0"):
+        """:505-511"""
+        check(_lib.load().pixie_mpm_finalize_mu_lam(self._h, 1, self._stream), "finalize_mu_lam_bulk")
+
+    def reset_densities_and_update_masses(self, all_particle_densities, device="cuda:0"):
+        """:640-656"""
+        self.set_field("density", all_particle_densities)
+        self._update_mass()
+
+    # ------------------------------------------------------------------ stepping
+    def p2g2p(self, step, dt, device="cuda:0"):
+        """:514-637 -- one substep; asynchronous on the current stream."""
+        check(_lib.load().pixie_mpm_step(self._h, float(dt), 1, self._stream), "pixie_mpm_step")
+
+    def run(self, dt, n_substeps):
+        """n substeps of p2g2p in one call (fused G2P->P2G launches, no host synchronisation)."""
+        check(_lib.load().pixie_mpm_step(self._h, float(dt), int(n_substeps), self._stream), "pixie_mpm_step")
+
+    p2g2p_n = run
+
+    def phase(self, phase, dt):
+        """Test hook: 0 = modifiers+stress+P2G, 1 = grid update+damping+BCs, 2 = G2P."""
+        check(_lib.load().pixie_mpm_phase(self._h, int(phase), float(dt), self._stream), "pixie_mpm_phase")
+
+    @property
+    def out_of_bounds(self):
+        cnt = C.c_int64(0)
+        check(_lib.load().pixie_mpm_out_of_bounds(self._h, C.byref(cnt), self._stream), "out_of_bounds")
+        return cnt.value
+
+    def set_profile(self, on=True):
+        self._set_scalar("profile", 1.0 if on else 0.0)
+
+    def kernel_times(self):
+        """(mean fused-particle-kernel ms, mean grid-kernel ms, launches) since the last call."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        check(_lib.load().pixie_mpm_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)), "kernel_times")
+        return a.value, b.value, n.value
+
+    # ------------------------------------------------------------------ import / export (:659-741)
+    def import_particle_x_from_torch(self, tensor_x, clone=True, device="cuda:0"):
+        if tensor_x is not None:
+            self.set_field("x", tensor_x)
+
+    def import_particle_v_from_torch(self, tensor_v, clone=True, device="cuda:0"):
+        if tensor_v is not None:
+            self.set_field("v", tensor_v)
+
+    def import_particle_F_from_torch(self, tensor_F, clone=True, device="cuda:0"):
+        if tensor_F is not None:
+            self.set_field("F", torch.reshape(tensor_F, (-1, 9)))
+
+    def import_particle_C_from_torch(self, tensor_C, clone=True, device="cuda:0"):
+        if tensor_C is not None:
+            self.set_field("C", torch.reshape(tensor_C, (-1, 9)))
+
+    def export_particle_x_to_torch(self):
+        return self.get_field("x")
+
+    def export_particle_v_to_torch(self):
+        return self.get_field("v")
+
+    def export_particle_stress_to_torch(self):
+        return self.get_field("stress").reshape(-1, 3, 3)
+
+    def export_particle_F_to_torch(self):
+        return self.get_field("F").reshape(-1, 9)
+
+    def export_particle_C_to_torch(self):
+        return self.get_field("C").reshape(-1, 9)
+
+    def export_particle_R_to_torch(self, device="cuda:0"):
+        out = torch.empty((self.n_particles, 9), dtype=torch.float32, device=self.device)
+        check(_lib.load().pixie_mpm_export_R(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_R")
+        return out
+
+    def export_particle_cov_to_torch(self, device="cuda:0"):
+        out = torch.empty(self.n_particles * 6, dtype=torch.float32, device=self.device)
+        check(_lib.load().pixie_mpm_export_cov(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_cov")
+        return out
+
+    def print_time_profile(self):
+        """:743-746"""
+        print("MPM Time profile:")
+        for key, value in self.time_profile.items():
+            print(key, sum(value))
+
+    # ------------------------------------------------------------------ boundary conditions
+    def _add_bc(self, **kw):
+        bc = BCDesc()
+        bc.type = kw["type"]
+        bc.surface_type = kw.get("surface_type", 0)
+        bc.reset = kw.get("reset", 0)
+        for nm in ("point", "size", "velocity", "normal"):
+            vals = kw.get(nm, (0.0, 0.0, 0.0))
+            for d in range(3):
+                getattr(bc, nm)[d] = float(vals[d])
+        bc.start_time = float(kw.get("start_time", 0.0))
+        bc.end_time = float(kw.get("end_time", 999.0))
+        bc.friction = float(kw.get("friction", 0.0))
+        check(_lib.load().pixie_mpm_add_bc(self._h, C.byref(bc)), "pixie_mpm_add_bc")
+
+    def add_surface_collider(self, point, normal, surface="sticky", friction=0.0, start_time=0.0, end_time=999.0):
+        """:749-843"""
+        point = list(point)
+        normal_scale = 1.0 / math.sqrt(float(sum(x ** 2 for x in normal)))
+        normal = list(normal_scale * x for x in normal)
+        if surface == "sticky" and friction != 0:
+            raise ValueError("friction must be 0 on sticky surfaces.")
+        surface_type = {"sticky": 0, "slip": 1, "cut": 11}.get(surface, 2)
+        self._add_bc(type=0, point=point, normal=normal, surface_type=surface_type, friction=friction,
+                     start_time=start_time, end_time=end_time)
+
+    def set_velocity_on_cuboid(self, point, size, velocity, start_time=0.0, end_time=999.0, reset=0):
+        """:853-908"""
+        self._add_bc(type=1, point=list(point), size=size, velocity=velocity, start_time=start_time,
+                     end_time=end_time, reset=reset)
+
+    def add_bounding_box(self, start_time=0.0, end_time=999.0):
+        """:910-977"""
+        self._add_bc(type=2, start_time=start_time, end_time=end_time)
+
+    def _add_pmod(self, **kw):
+        pm = PModDesc()
+        pm.type = kw["type"]
+        for nm in ("point", "size", "force", "velocity", "normal", "h1", "h2"):
+            vals = kw.get(nm, (0.0, 0.0, 0.0))
+            for d in range(3):
+                getattr(pm, nm)[d] = float(vals[d])
+        for nm in ("half_height", "radius", "rotation_scale", "translation_scale", "start_time", "end_time"):
+            setattr(pm, nm, float(kw.get(nm, 0.0)))
+        check(_lib.load().pixie_mpm_add_particle_modifier(self._h, C.byref(pm), self._stream), "add_particle_modifier")
+
+    def add_impulse_on_particles(self, force, dt, point=[1, 1, 1], size=[1, 1, 1], num_dt=1, start_time=0.0,
+                                 device="cuda:0"):
+        """:982-1029"""
+        self._add_pmod(type=0, force=force, point=point, size=size, start_time=start_time,
+                       end_time=start_time + dt * num_dt)
+
+    def enforce_particle_velocity_translation(self, point, size, velocity, start_time, end_time, device="cuda:0"):
+        """:1031-1075"""
+        self._add_pmod(type=1, point=point, size=size, velocity=velocity, start_time=start_time, end_time=end_time)
+
+    def enforce_particle_velocity_rotation(self, point, normal, half_height_and_radius, rotation_scale,
+                                           translation_scale, start_time, end_time, device="cuda:0"):
+        """:1080-1181 (axis set-up :1092-1117 in float32, as wp.vec3 arithmetic)"""
+        n = np.asarray(normal, dtype=np.float64)
+        n = (n * (1.0 / math.sqrt(float(n[0] ** 2 + n[1] ** 2 + n[2] ** 2)))).astype(np.float32)
+        h1 = np.array([1.0, 1.0, 1.0], np.float32)
+        if abs(float(np.dot(n, h1))) < 0.01:
+            h1 = np.array([0.72, 0.37, -0.67], np.float32)
+        h1 = h1 - np.float32(np.dot(h1, n)) * n
+        h1 = h1 * np.float32(1.0 / np.linalg.norm(h1))
+        h2 = np.cross(h1, n).astype(np.float32)
+        self._add_pmod(type=2, point=point, normal=n, h1=h1, h2=h2, half_height=half_height_and_radius[0],
+                       radius=half_height_and_radius[1], rotation_scale=rotation_scale,
+                       translation_scale=translation_scale, start_time=start_time, end_time=end_time)
+
+    def release_particles_sequentially(self, normal, start_position, end_position, num_layers, start_time, end_time):
+        """:1185-1210"""
+        num_layers = 50
+        point = [0, 0, 0]
+        size = [0, 0, 0]
+        axis = -1
+        for i in range(3):
+            if normal[i] == 0:
+                point[i] = 1
+                size[i] = 1
+            else:
+                axis = i
+                point[i] = end_position
+        half_length_portion = abs(start_position - end_position) / num_layers
+        end_time_portion = end_time / num_layers
+        for i in range(num_layers):
+            size[axis] = half_length_portion * (num_layers - i)
+            self.enforce_particle_velocity_translation(point=point, size=size, velocity=[0, 0, 0],
+                                                       start_time=start_time, end_time=end_time_portion * (i + 1))

@@ -1,0 +1,114 @@
+"""Seeded synthetic inputs for the hot path.
+
+No datasets or checkpoints exist offline, and the reference's spatial LayerNorm
+affine parameters are grid-size-shaped (diffusion_network.py:674,679,870), so the
+BASELINE configurations run on synthetic grids, weights and particle scenes
+generated here.  Everything is numpy (CPU, deterministic across machines).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------- MPM
+def mpm_ball_scene(n_particles: int = 100_000, seed: int = 0, n_grid: int = 50, grid_lim: float = 2.0,
+                   dt: float = 1e-4, scenario: str = "tree"):
+    """BASELINE config 3/5 particle scene.
+
+    Particles uniform in the ball of radius 0.5 centred (1,1,1) -- the frame the
+    reference driver leaves particles in after transform2origin + shift2center111
+    (PhysGaussian/utils/transformation_utils.py:6-16,103-105).  Material 0 ("jelly",
+    fixed-corotated) with per-particle E = 10^U(5,6.3), nu = U(0.2,0.4), rho = U(200,2000).
+
+    scenario "tree"  mirrors PhysGaussian/config/objaverse/custom_tree_config.json:
+        g = 0, grid_v_damping_scale 0.9999, rpic 0, one particle_impulse (-0.48,0,0) for 1 dt,
+        plus the fix_to_ground slab (material_field.py:485-550: delta_z 0.05, buffer_xy 0.5).
+    scenario "ball"  mirrors custom_sport_balls_config.json: g = (0,0,-9.8), bounding_box.
+    """
+    rng = np.random.default_rng(seed)
+    # rejection-free uniform ball sampling
+    d = rng.normal(size=(n_particles, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = 0.5 * rng.random(n_particles) ** (1.0 / 3.0)
+    x = (1.0 + d * r[:, None]).astype(np.float32)
+    vol = np.full(n_particles, (4.0 / 3.0) * math.pi * 0.5 ** 3 / n_particles, np.float32)
+    E = (10.0 ** rng.uniform(5.0, 6.3, n_particles)).astype(np.float32)
+    nu = rng.uniform(0.2, 0.4, n_particles).astype(np.float32)
+    rho = rng.uniform(200.0, 2000.0, n_particles).astype(np.float32)
+    # isotropic initial covariances (6-float upper triangles xx,xy,xz,yy,yz,zz)
+    s2 = rng.uniform(1e-5, 4e-5, n_particles).astype(np.float32)
+    cov = np.zeros((n_particles, 6), np.float32)
+    cov[:, 0] = s2; cov[:, 3] = s2; cov[:, 5] = s2
+
+    scene = dict(x=x, vol=vol, cov=cov, E=E, nu=nu, density=rho, material=np.zeros(n_particles, np.int32),
+                 n_grid=n_grid, grid_lim=grid_lim, dt=dt)
+    if scenario == "tree":
+        scene["params"] = dict(material="jelly", g=[0.0, 0.0, 0.0], grid_v_damping_scale=0.9999, rpic_damping=0.0,
+                               E=2e6, nu=0.4, density=200.0)
+        scene["bcs"] = [dict(type="particle_impulse", force=[-0.48, 0.0, 0.0], num_dt=1, start_time=0.0)]
+        scene["fix_ground"] = dict(delta_z=0.05, buffer_xy=0.5)
+    elif scenario == "ball":
+        scene["params"] = dict(material="jelly", g=[0.0, 0.0, -9.8], E=4e4, nu=0.4, density=200.0)
+        scene["bcs"] = [dict(type="bounding_box")]
+        scene["fix_ground"] = None
+    else:
+        raise ValueError(scenario)
+    return scene
+
+
+def ground_slab(positions: np.ndarray, delta_z: float = 0.02, buffer_xy: float = 0.5):
+    """Cuboid of fix_to_ground (PhysGaussian/material_field.py:485-550), min_z_percentile=1."""
+    min_xy = positions[:, :2].min(axis=0)
+    max_xy = positions[:, :2].max(axis=0)
+    size_xy = max_xy - min_xy
+    min_z = positions[:, 2].min()
+    center = [float((min_xy[0] + max_xy[0]) / 2), float((min_xy[1] + max_xy[1]) / 2), float(min_z + delta_z / 2)]
+    half = [float(size_xy[0] / 2 + buffer_xy), float(size_xy[1] / 2 + buffer_xy), float(delta_z / 2)]
+    return dict(point=center, size=half, velocity=[0.0, 0.0, 0.0], start_time=0.0, end_time=1e6, reset=1)
+
+
+def apply_scene(solver, scene, per_particle: bool = True):
+    """Drive any solver exposing the reference's MPM_Simulator_WARP method names
+    (the HIP solver or the oracle) through the set-up order of gs_simulation.py:483-531."""
+    solver.set_parameters_dict(scene["params"])
+    for bc in scene["bcs"]:
+        if bc["type"] == "particle_impulse":
+            solver.add_impulse_on_particles(force=bc["force"], dt=scene["dt"], point=bc.get("point", [1, 1, 1]),
+                                            size=bc.get("size", [1, 1, 1]), num_dt=bc.get("num_dt", 1),
+                                            start_time=bc.get("start_time", 0.0))
+        elif bc["type"] == "bounding_box":
+            solver.add_bounding_box()
+        elif bc["type"] == "cuboid":
+            solver.set_velocity_on_cuboid(point=bc["point"], size=bc["size"], velocity=bc["velocity"],
+                                          start_time=bc.get("start_time", 0.0), end_time=bc.get("end_time", 1e3),
+                                          reset=bc.get("reset", 0))
+        elif bc["type"] == "surface_collider":
+            solver.add_surface_collider(point=bc["point"], normal=bc["normal"], surface=bc["surface"],
+                                        friction=bc["friction"], start_time=bc["start_time"], end_time=bc["end_time"])
+        elif bc["type"] == "enforce_particle_translation":
+            solver.enforce_particle_velocity_translation(point=bc["point"], size=bc["size"], velocity=bc["velocity"],
+                                                         start_time=bc["start_time"], end_time=bc["end_time"])
+        else:
+            raise TypeError("Undefined BC type")
+    if scene.get("fix_ground"):
+        slab = ground_slab(scene["x"], **scene["fix_ground"])
+        solver.set_velocity_on_cuboid(**slab)
+    if per_particle:
+        solver.set_per_particle(E=scene["E"], nu=scene["nu"], density=scene["density"], material=scene["material"])
+    solver.finalize_mu_lam()
+
+
+# --------------------------------------------------------------------------- U-Net
+def feature_grid(D: int, C: int = 64, seed: int = 0, occupancy: bool = False) -> np.ndarray:
+    """(1,C,D,D,D) float32 feature grid; `occupancy` masks to a ball of radius 0.35 D and
+    rounds through fp16 as the reference stores features (pixie/voxel/voxelize.py:86,111)."""
+    rng = np.random.default_rng(seed)
+    feat = rng.standard_normal((1, C, D, D, D), dtype=np.float32)
+    if occupancy:
+        g = np.arange(D, dtype=np.float32) - (D - 1) / 2.0
+        rr = g[:, None, None] ** 2 + g[None, :, None] ** 2 + g[None, None, :] ** 2
+        feat *= (rr <= (0.35 * D) ** 2)[None, None]
+        feat = feat.astype(np.float16).astype(np.float32)
+    return feat
