@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""Benchmark of the material_mode=neural hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one scene through the U-Net stage of the hot path: SegmentationUNet + RegressionUNet
+forward on a device-resident 128^3 x 64 feature grid (BASELINE.json configs[1]) + argmax/one-hot
+combine, and (N > 1) the all-gather of the compact fields.  `value` = voxels/s over all ranks
+(weak scaling: one scene per rank per step).  The MPM half of the metric (BASELINE configs[2]:
+100k particles, n_grid 50) is timed in the same run and reported under "mpm" with its own roofline.
+Synthetic data and seeded random-init weights (no datasets/checkpoints exist offline).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from pixie_amd import distributed as pd  # noqa: E402
+from pixie_amd.synthetic import apply_scene, feature_grid, mpm_ball_scene  # noqa: E402
+from pixie_amd.unet_plan import UNetConfig, conv_flops, synthetic_state_dict  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec (6.3 TB/s achievable per the same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=128, help="U-Net grid size D (BASELINE config: 128)")
+    ap.add_argument("--feature-channels", type=int, default=64)
+    ap.add_argument("--particles", type=int, default=100_000)
+    ap.add_argument("--n-grid", type=int, default=50)
+    ap.add_argument("--mpm-substeps", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mpm", action="store_true")
+    return ap.parse_args()
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds: float, world: int, device) -> float:
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+class ConvProfiler:
+    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream),
+    recorded live inside the timed region; aggregated per layer shape afterwards."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ops):
+        inner = ops.conv
+        prof = self
+
+        def conv(parts, packed_w, bias, cout, ksize, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner(parts, packed_w, bias, cout, ksize, **kw)
+            e1.record()
+            cin = sum(int(p.shape[0]) for p in parts)
+            prof.records.append(((cin, cout, ksize, kw.get("stride", 1), bool(kw.get("upsample", False)), tuple(out.shape[1:])), e0, e1))
+            return out
+
+        ops.conv = conv
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(key, [0.0, 0])
+            a[0] += ms; a[1] += 1
+        return agg
+
+
+def bench_unet(args, rank, world, device):
+    from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
+    D, C = args.grid, args.feature_channels
+    kw = dict(feature_channels=C, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4),
+              attention_resolutions=(), grid_size=D)
+    seg = SegmentationUNet(num_classes=8, **kw)
+    cont = RegressionUNet(out_channels=3, **kw)
+    seg.load_numpy_state(synthetic_state_dict(seg.cfg, 0))
+    cont.load_numpy_state(synthetic_state_dict(cont.cfg, 1000))
+    seg, cont = seg.to(device).eval(), cont.to(device).eval()
+    feat = torch.from_numpy(feature_grid(D, C, seed=100 + rank)).to(device)  # scene i uses seed 100+i
+
+    def step():
+        combined, seg_pred, _, cont_pred = predict_material_field(seg, cont, feat)
+        if world > 1:
+            pd.all_gather_fields(cont_pred, seg_pred)
+        return combined
+
+    for _ in range(args.warmup):
+        step()
+    prof = ConvProfiler()
+    prof.wrap(seg._runner.ops)   # both networks share one HipOps instance per device? no: wrap both
+    if cont._runner.ops is not seg._runner.ops:
+        prof.wrap(cont._runner.ops)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, device)
+    flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
+    # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution)
+    agg = prof.summary()
+    dom_key = (64, 64, 3, 1, False, (D, D, D))
+    roof = None
+    if dom_key in agg:
+        ms = agg[dom_key][0] / agg[dom_key][1]
+        fl = 2.0 * 27 * 64 * 64 * D ** 3
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,2,4,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
+    conv_ms = sum(v[0] for v in agg.values()) / max(args.steps, 1)
+    return dict(seconds=dt, voxels=world * args.steps * D ** 3, flops_scene=flops_scene, roofline=roof,
+                conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(args.steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]})
+
+
+def bench_mpm(args, rank, world, device):
+    from pixie_amd.mpm_solver import MPM_Simulator_WARP
+    sc = mpm_ball_scene(args.particles, seed=rank, n_grid=args.n_grid)
+    s = MPM_Simulator_WARP(10)
+    s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
+                                   n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
+    apply_scene(s, sc)
+    s.run(sc["dt"], 50)  # warm-up
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    s.run(sc["dt"], args.mpm_substeps)
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, device)
+    # separate short pass with per-launch HIP events on the launch stream for the roofline of the fused particle kernel
+    s.set_profile(True)
+    s.run(sc["dt"], 200)
+    torch.cuda.synchronize()
+    p_ms, g_ms, n_launch = s.kernel_times()
+    s.set_profile(False)
+    alg_bytes = 212.0 * args.particles + 44.0 * args.n_grid ** 3  # SURVEY.md section 8d (fused minimum, dense grid)
+    part_bytes = 212.0 * args.particles
+    ach = part_bytes / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": "mpm_particle_kernel<G2P,P2G> (fused gather + stress + scatter)", "achieved": round(ach, 1),
+            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None,
+            "avg_launch_ms": round(p_ms, 5), "grid_kernel_ms": round(g_ms, 5), "launches": int(n_launch),
+            "bytes_per_launch": part_bytes, "substep_algorithmic_bytes": alg_bytes}
+    oob = s.out_of_bounds
+    finite = bool(torch.isfinite(s.get_field("x")).all())
+    return dict(seconds=dt, particle_steps=world * args.particles * args.mpm_substeps, roofline=roof, alg_bytes=alg_bytes,
+                oob=oob, finite=finite)
+
+
+def cpu_baselines(args):
+    """The oracle (a port: oracle/unet_oracle.py on PyTorch CPU kernels, oracle/mpm_oracle.c scalar C)
+    timed on this box's host cores on a bounded sample.  Reported next to the GPU numbers, not a target."""
+    from oracle import unet_oracle
+    from oracle.mpm_oracle import OracleMPM
+    out = {}
+    Dc = 64 if args.grid >= 64 else args.grid
+    feat = feature_grid(Dc, args.feature_channels, seed=100)
+    nets = []
+    for oc, ws in ((8, 0), (3, 1000)):
+        cfg = UNetConfig(feature_channels=args.feature_channels, grid_size=Dc, out_channels=oc)
+        nets.append((cfg, synthetic_state_dict(cfg, ws)))
+    t0 = time.perf_counter()
+    for cfg, sd in nets:
+        unet_oracle.unet_forward(sd, cfg, feat)
+    dt = time.perf_counter() - t0
+    out["unet"] = {"value": Dc ** 3 / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{Dc}^3x{args.feature_channels} grid, SegmentationUNet+RegressionUNet forward once on PyTorch CPU"}
+    n = min(args.particles, 100_000)
+    sc = mpm_ball_scene(n, seed=0, n_grid=args.n_grid)
+    o = OracleMPM(n, sc["n_grid"], sc["grid_lim"], "f32")
+    o.load_initial_data(sc["x"], sc["vol"], sc["cov"])
+    apply_scene(o, sc)
+    steps = 40
+    t0 = time.perf_counter()
+    o.run(sc["dt"], steps)
+    dt = time.perf_counter() - t0
+    out["mpm"] = {"value": n * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+                  "sample": f"{n} particles, n_grid {args.n_grid}, {steps} substeps, scalar C oracle"}
+    return out
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (pixie_amd has no CPU path)")
+    rank, world, local = pd.init_process_group()
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    u = bench_unet(args, rank, world, device)
+    m = None if args.no_mpm else bench_mpm(args, rank, world, device)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baselines(args)
+
+    if rank == 0:
+        vps = u["voxels"] / u["seconds"]
+        line = {
+            "metric": "voxels/s (128^3 U-Net fwd) + MPM particle-steps/s",
+            "value": vps, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * u["seconds"] / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.grid}^3x{args.feature_channels} feature grid -> SegmentationUNet+RegressionUNet forward "
+                                   f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
+                       "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
+                       "weights": "seeded random init of the reference architecture"},
+            "unet_tflops": u["flops_scene"] * world * args.steps / u["seconds"] / 1e12,
+            "unet_conv_ms_per_step": u["conv_ms_per_step"],
+            "roofline": u["roofline"],
+        }
+        if m is not None:
+            ps = m["particle_steps"] / m["seconds"]
+            line["mpm"] = {
+                "value": ps, "unit": "particle-steps/s", "substeps": args.mpm_substeps,
+                "us_per_substep": 1e6 * m["seconds"] / args.mpm_substeps,
+                "config": {"workload": f"{args.particles} particles, n_grid {args.n_grid}, grid_lim 2, dt 1e-4, jelly ball, tree scenario "
+                                       "(impulse + ground slab), 1 scene per GPU"},
+                "algorithmic_GBps": m["alg_bytes"] * args.mpm_substeps * world / m["seconds"] / 1e9 / world,
+                "frac_of_hbm_roofline_per_gpu": m["alg_bytes"] * args.mpm_substeps / m["seconds"] / 1e9 / PEAK_HBM_GBPS,
+                "roofline": m["roofline"], "finite": m["finite"], "out_of_bounds": m["oob"],
+            }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu["unet"]
+            if "mpm" in line:
+                line["mpm"]["cpu_baseline"] = cpu["mpm"]
+        line["layer_ms_top"] = u["layer_ms"]
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

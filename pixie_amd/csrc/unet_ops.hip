@@ -1,0 +1,279 @@
+// pixie_amd/csrc/unet_ops.hip -- the non-convolution operators of the U-Net path on gfx950.
+//
+//  channel sums + finalize   statistics of nn.LayerNorm([D,H,W]) (diffusion_network.py:674,679,870) and
+//                            nn.GroupNorm / GroupNorm32 (:571-584; nn.py:17-19, :199) reduced to the
+//                            per-channel (a,b) that the conv kernel's prologue applies, so that no
+//                            normalised tensor is ever written to HBM;
+//  attention                 QKVAttention.forward (diffusion_network.py:224-242), streamed softmax;
+//  combine                   argmax + one-hot + concat of inference_combined.py:124-126,186-195.
+#include <hip/hip_runtime.h>
+
+#include "../../include/pixie_hip.h"
+#include "common.h"
+
+namespace pixie {
+
+// ---------------------------------------------------------------- per-channel sum / sum of squares
+// grid = (splits, channels); each block reduces one contiguous segment of one channel with float4
+// loads (HBM-bound: one read of the tensor), fp32 per-thread partials over <= a few hundred
+// elements, fp64 from the block reduction on, one fp64 atomic pair per block.
+__global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ x, long spatial, long seg, double* __restrict__ sums) {
+    const int c = blockIdx.y;
+    const long begin = (long)blockIdx.x * seg;
+    const long end = begin + seg < spatial ? begin + seg : spatial;
+    const float* p = x + (size_t)c * spatial;
+    double s1 = 0.0, s2 = 0.0;
+    const bool vec_ok = ((reinterpret_cast<size_t>(p + begin) & 15) == 0);
+    long i = begin + (long)threadIdx.x * 4;
+    if (vec_ok) {
+        float a1 = 0.f, a2 = 0.f;
+        int cnt = 0;
+        for (; i + 3 < end; i += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            a1 += (v.x + v.y) + (v.z + v.w);
+            a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            if (++cnt == 64) { s1 += a1; s2 += a2; a1 = 0.f; a2 = 0.f; cnt = 0; }
+        }
+        s1 += a1; s2 += a2;
+        for (long k = i; k < end && k < i + 4; ++k) { const float v = p[k]; s1 += v; s2 += (double)v * v; }
+    } else {
+        for (long k = begin + threadIdx.x; k < end; k += 256) { const float v = p[k]; s1 += v; s2 += (double)v * v; }
+    }
+    // wave reduce (64 lanes) then across the 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t1 = red[0] + red[2] + red[4] + red[6];
+        const double t2 = red[1] + red[3] + red[5] + red[7];
+        atomicAdd(&sums[2 * c], t1);
+        atomicAdd(&sums[2 * c + 1], t2);
+    }
+}
+
+// mode 0: per-channel LayerNorm statistics (biased variance, eps inside the sqrt -- torch semantics)
+// mode 1: GroupNorm(groups): statistics over (channels/groups) x spatial, affine folded per channel
+__global__ void norm_finalize_kernel(const double* __restrict__ sums, int channels, double spatial, int mode, int groups, double eps,
+                                     const float* __restrict__ weight, const float* __restrict__ bias, float* __restrict__ a,
+                                     float* __restrict__ b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= channels) return;
+    double mean, var;
+    if (mode == 0) {
+        mean = sums[2 * c] / spatial;
+        var = sums[2 * c + 1] / spatial - mean * mean;
+    } else {
+        const int cpg = channels / groups;
+        const int g = c / cpg;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s1 += sums[2 * k]; s2 += sums[2 * k + 1]; }
+        const double cnt = spatial * cpg;
+        mean = s1 / cnt;
+        var = s2 / cnt - mean * mean;
+    }
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    if (mode == 0) {
+        a[c] = (float)rstd;
+        b[c] = (float)(-mean * rstd);
+    } else {
+        const double w = weight ? (double)weight[c] : 1.0;
+        const double bb = bias ? (double)bias[c] : 0.0;
+        a[c] = (float)(rstd * w);
+        b[c] = (float)(bb - mean * rstd * w);
+    }
+}
+
+__global__ void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                      float* __restrict__ y, long spatial, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i / spatial);
+    y[i] = x[i] * a[c] + b[c];
+}
+
+// ---------------------------------------------------------------- attention
+// qkv is [3C][T] (q rows 0..C-1, k rows C..2C-1, v rows 2C..3C-1); out[c][t] = sum_s softmax_s(q_t . k_s * C^-1/2) v[c][s].
+// Workgroup = 256 threads handles BQ = 16 queries; keys/values stream through LDS in tiles of BS = 32
+// with the running (max, sum) rescaling of a streamed softmax, so no T x T logits exist anywhere
+// (the reference materialises them: 64 MiB at 128^3, 4 GiB at 256^3).
+constexpr int ATT_BQ = 16;
+constexpr int ATT_BS = 32;
+template <int C>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;                      // [C][BQ]
+    float* Ks = Qs + C * ATT_BQ;         // [C][BS]
+    float* Vs = Ks + C * ATT_BS;         // [C][BS]
+    float* Ps = Vs + C * ATT_BS;         // [BQ][BS+1]
+    float* rowm = Ps + ATT_BQ * (ATT_BS + 1);   // [BQ] running max
+    float* rowl = rowm + ATT_BQ;                // [BQ] running sum
+    float* rowf = rowl + ATT_BQ;                // [BQ] rescale factor of this tile
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * ATT_BQ;
+    const float* q = qkv;
+    const float* k = qkv + (size_t)C * T;
+    const float* v = qkv + (size_t)2 * C * T;
+    const float scale2 = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, diffusion_network.py:233-236
+
+    for (int i = tid; i < C * ATT_BQ; i += 256) {
+        const int c = i / ATT_BQ, qi = i % ATT_BQ;
+        Qs[i] = (t0 + qi < T) ? q[(size_t)c * T + t0 + qi] * scale2 : 0.0f;
+    }
+    if (tid < ATT_BQ) { rowm[tid] = -3.0e38f; rowl[tid] = 0.0f; }
+    constexpr int CPT = C / 16;  // output channels per thread
+    float acc[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) acc[i] = 0.0f;
+    const int qi = tid & 15;
+    const int grp = tid >> 4;  // 0..15: key lane for the score phase, channel group for the PV phase
+    __syncthreads();
+
+    for (int s0 = 0; s0 < T; s0 += ATT_BS) {
+        for (int i = tid; i < C * ATT_BS; i += 256) {
+            const int c = i / ATT_BS, sj = i % ATT_BS;
+            const bool ok = s0 + sj < T;
+            Ks[i] = ok ? k[(size_t)c * T + s0 + sj] : 0.0f;
+            Vs[i] = ok ? v[(size_t)c * T + s0 + sj] : 0.0f;
+        }
+        __syncthreads();
+        // scores: thread (qi, grp) -> keys grp and grp+16
+        float sc0 = 0.0f, sc1 = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float qv = Qs[c * ATT_BQ + qi];
+            sc0 += qv * Ks[c * ATT_BS + grp];
+            sc1 += qv * Ks[c * ATT_BS + grp + 16];
+        }
+        if (s0 + grp >= T) sc0 = -3.0e38f;
+        if (s0 + grp + 16 >= T) sc1 = -3.0e38f;
+        Ps[qi * (ATT_BS + 1) + grp] = sc0;
+        Ps[qi * (ATT_BS + 1) + grp + 16] = sc1;
+        __syncthreads();
+        if (tid < ATT_BQ) {  // one thread per query row: new max, rescale factor, exponentials, sum
+            float m = rowm[tid];
+            float mx = m;
+            for (int j = 0; j < ATT_BS; ++j) mx = fmaxf(mx, Ps[tid * (ATT_BS + 1) + j]);
+            const float f = __expf(m - mx);
+            float l = rowl[tid] * f;
+            for (int j = 0; j < ATT_BS; ++j) {
+                const float sv = Ps[tid * (ATT_BS + 1) + j];
+                const float e = (sv <= -1.0e38f) ? 0.0f : __expf(sv - mx);
+                Ps[tid * (ATT_BS + 1) + j] = e;
+                l += e;
+            }
+            rowm[tid] = mx; rowl[tid] = l; rowf[tid] = f;
+        }
+        __syncthreads();
+        // PV: thread (qi, grp) owns channels grp*CPT .. grp*CPT+CPT-1 of query qi
+        const float f = rowf[qi];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) acc[i] *= f;
+        for (int j = 0; j < ATT_BS; ++j) {
+            const float pj = Ps[qi * (ATT_BS + 1) + j];
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) acc[i] += pj * Vs[(grp * CPT + i) * ATT_BS + j];
+        }
+        __syncthreads();
+    }
+    if (t0 + qi < T) {
+        const float inv = 1.0f / rowl[qi];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) out[(size_t)(grp * CPT + i) * T + t0 + qi] = acc[i] * inv;
+    }
+}
+
+// ---------------------------------------------------------------- argmax + one-hot + concat
+__global__ void combine_kernel(const float* __restrict__ logits, int ncls, const float* __restrict__ cont, long spatial,
+                               float* __restrict__ combined, int* __restrict__ argmax_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= spatial) return;
+    int best = 0;
+    float bv = logits[i];
+    for (int c = 1; c < ncls; ++c) {
+        const float v = logits[(size_t)c * spatial + i];
+        if (v > bv) { bv = v; best = c; }  // first maximum wins, as torch.argmax
+    }
+    for (int c = 0; c < 3; ++c) combined[(size_t)c * spatial + i] = cont[(size_t)c * spatial + i];
+    for (int c = 0; c < ncls; ++c) combined[(size_t)(3 + c) * spatial + i] = (c == best) ? 1.0f : 0.0f;
+    if (argmax_out) argmax_out[i] = best;
+}
+
+template <int C>
+static int launch_attention(const float* qkv, float* out, int T, hipStream_t st) {
+    const size_t lds = ((size_t)C * ATT_BQ + 2 * (size_t)C * ATT_BS + ATT_BQ * (ATT_BS + 1) + 3 * ATT_BQ) * sizeof(float);
+    auto kern = attention_kernel<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((T + ATT_BQ - 1) / ATT_BQ), dim3(256), lds, st, qkv, out, T);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pixie
+
+using namespace pixie;
+
+extern "C" int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream) {
+    PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_sums: bad arguments");
+    hipStream_t st = as_stream(stream);
+    PX_CHECK_HIP(hipMemsetAsync(d_sums, 0, (size_t)channels * 2 * sizeof(double), st));
+    // segments of >= 16 Ki elements, at most ~2048 blocks in total
+    long splits = (spatial + 16383) / 16384;
+    const long max_splits = std::max(1L, 2048L / channels);
+    if (splits > max_splits) splits = max_splits;
+    long seg = (spatial + splits - 1) / splits;
+    seg = (seg + 3) & ~3L;  // keep float4 alignment of segment starts
+    splits = (spatial + seg - 1) / seg;
+    hipLaunchKernelGGL(channel_sums_kernel, dim3((unsigned)splits, (unsigned)channels), dim3(256), 0, st, d_x, (long)spatial, seg, d_sums);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pixie_norm_finalize(const double* d_sums, int channels, int64_t spatial, int mode, int groups, double eps,
+                                   const float* d_weight, const float* d_bias, float* d_a, float* d_b, void* stream) {
+    PX_REQUIRE(d_sums && d_a && d_b && channels > 0 && spatial > 0, "pixie_norm_finalize: bad arguments");
+    PX_REQUIRE(mode == 0 || (mode == 1 && groups > 0 && channels % groups == 0), "pixie_norm_finalize: bad mode/groups");
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(channels, 64)), dim3(64), 0, as_stream(stream), d_sums, channels, (double)spatial,
+                       mode, groups, eps, d_weight, d_bias, d_a, d_b);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pixie_channel_affine(const float* d_x, const float* d_a, const float* d_b, float* d_y, int channels, int64_t spatial,
+                                    void* stream) {
+    PX_REQUIRE(d_x && d_a && d_b && d_y, "pixie_channel_affine: null argument");
+    const long total = (long)channels * spatial;
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), d_x, d_a, d_b, d_y, (long)spatial, total);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pixie_attention_forward(const float* d_qkv, float* d_out, int channels, int tokens, void* stream) {
+    PX_REQUIRE(d_qkv && d_out && tokens > 0, "pixie_attention_forward: bad arguments");
+    hipStream_t st = as_stream(stream);
+    switch (channels) {
+        case 32: return launch_attention<32>(d_qkv, d_out, tokens, st);
+        case 64: return launch_attention<64>(d_qkv, d_out, tokens, st);
+        case 128: return launch_attention<128>(d_qkv, d_out, tokens, st);
+        case 256: return launch_attention<256>(d_qkv, d_out, tokens, st);
+        default: return set_error("pixie_attention_forward: unsupported channel count %d (32/64/128/256)", channels);
+    }
+}
+
+extern "C" int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial, float* d_combined,
+                                         int32_t* d_argmax, void* stream) {
+    PX_REQUIRE(d_logits && d_cont && d_combined && num_classes > 0 && spatial > 0, "pixie_combine_predictions: bad arguments");
+    hipLaunchKernelGGL(combine_kernel, dim3(cdiv(spatial, 256)), dim3(256), 0, as_stream(stream), d_logits, num_classes, d_cont, (long)spatial,
+                       d_combined, d_argmax);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}

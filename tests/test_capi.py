@@ -1,0 +1,64 @@
+"""CPU checks of the drop-in boundary: the shared library loads and exports every symbol that
+include/pixie_hip.h declares, struct layouts match, and the product refuses to run without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from pixie_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "pixie_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pixie_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 28
+    for nm in names:
+        assert hasattr(lib, nm), f"{nm} declared in include/pixie_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.pixie_build_arch() == b"gfx950"
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by the C declarations (natural alignment)
+    assert C.sizeof(_lib.BCDesc) == 16 + 12 * 8 + 3 * 8
+    assert C.sizeof(_lib.PModDesc) == 8 + 21 * 8 + 6 * 8
+    assert C.sizeof(_lib.ConvDesc) % 8 == 0 and _lib.ConvDesc.d_out.offset == C.sizeof(_lib.ConvDesc) - 8
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device failure mode")
+def test_fails_loudly_without_a_device():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.pixie_mpm_create(C.byref(h), 8, 8, 1.0) != 0
+    assert b"hipMalloc" in lib.pixie_last_error() or b"device" in lib.pixie_last_error()
+    from pixie_amd.mpm_solver import MPM_Simulator_WARP
+    with pytest.raises(_lib.PixieHipError):
+        MPM_Simulator_WARP(8, n_grid=8)
+    from pixie_amd.unet import RegressionUNet
+    m = RegressionUNet(32, 32, 32, 1, (1, 2), (), 8)
+    with pytest.raises(_lib.PixieHipError):
+        m(torch.zeros(1, 32, 8, 8, 8))
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "pixie_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/ on the CPU", ""), f
+
+
+def test_reference_material_name_quirk():
+    from pixie_amd.mpm_solver import NAME_TO_MATERIAL_ID, get_material_id, get_material_name
+    assert get_material_name("sand") == 2 and get_material_name("visplas") == -1 and get_material_id("snow") == 5
+    assert NAME_TO_MATERIAL_ID["stationary"] == 6 and "fluid" not in NAME_TO_MATERIAL_ID

@@ -1,0 +1,64 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: scene sharding == DistributedSampler, and the
+field all-gather round-trips the compact wire format."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch.utils.data.distributed import DistributedSampler
+
+from pixie_amd import distributed as pd
+
+
+@pytest.mark.parametrize("n,world", [(8, 2), (7, 2), (5, 4), (1, 2), (16, 8), (3, 8)])
+def test_shard_equals_distributed_sampler(n, world):
+    ds = list(range(n))
+    for r in range(world):
+        want = list(DistributedSampler(ds, num_replicas=world, rank=r, shuffle=False))
+        assert pd.shard_scenes(n, r, world) == want
+    order = pd.unshard_order(n, world)
+    gathered = sum((pd.shard_scenes(n, r, world) for r in range(world)), [])
+    assert [gathered[p] for p in order] == list(range(n))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_scenes, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    pd.init_process_group("gloo")
+    mine = pd.shard_scenes(n_scenes, rank, world)
+    D = 6
+    cont = torch.stack([torch.full((3, D, D, D), float(s)) + torch.arange(3.0)[:, None, None, None] for s in mine])
+    seg = torch.stack([torch.full((D, D, D), s % 8, dtype=torch.int32) for s in mine])
+    g_cont, g_seg = pd.all_gather_fields(cont, seg)
+    order = pd.unshard_order(n_scenes, world)
+    ok = g_cont.shape == (world * len(mine), 3, D, D, D) and g_seg.dtype == torch.uint8
+    for i in range(n_scenes):
+        ok = ok and float(g_cont[order[i], 0, 0, 0, 0]) == float(i) and float(g_cont[order[i], 2, 1, 1, 1]) == i + 2.0
+        ok = ok and int(g_seg[order[i], 0, 0, 0]) == i % 8
+    comb = pd.combined_from_wire(g_cont, g_seg)
+    ok = ok and comb.shape == (world * len(mine), 11, D, D, D) and bool(torch.all(comb[:, 3:].sum(1) == 1))
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scenes", [4, 3])
+def test_all_gather_fields_gloo_world2(n_scenes):
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, n_scenes, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_single_process_passthrough():
+    cont = torch.randn(2, 3, 4, 4, 4); seg = torch.randint(0, 8, (2, 4, 4, 4))
+    c, s = pd.all_gather_fields(cont, seg)
+    assert torch.equal(c, cont) and s.dtype == torch.uint8 and torch.equal(s.long(), seg)
