@@ -6,19 +6,29 @@
 //   grid_normalization_and_gravity -> add_damping_via_grid -> BC collide x k -> g2p
 // (6-10 launches + 5 forced device syncs per substep) by TWO launches per substep and no syncs:
 //
-//   particle kernel <G2P,P2G>:  G2P of substep t  ->  modifiers, return map + stress, P2G of
-//                               substep t+1.  F_trial, stress, C' and the new v never leave
-//                               registers between the gather and the scatter.
-//   grid kernel:                normalise + gravity + damping + every BC in one sweep, and
-//                               clears (m, m*v) behind itself so no separate zero_grid runs.
+//   block kernel <G2P,P2G>:  G2P of substep t  ->  modifiers, return map + stress, P2G of
+//                            substep t+1.  F_trial, stress, C' and the new v never leave registers
+//                            between the gather and the scatter (in the fused form v and C are not
+//                            even stored: nothing reads them before the next G2P overwrites them).
+//   grid kernel:             normalise + gravity + damping + every BC in one sweep, and
+//                            clears (m, m*v) behind itself so no separate zero_grid runs.
 //
-// Layout in HBM: particle state is SoA fp32 ([component][particle], each component stream is a
-// fully coalesced 256 B/wave access); the grid is two float4 arrays: gin = (m*v.xyz, m) that
-// P2G accumulates with hardware fp32 atomics, gout = (v.xyz, 0) that G2P gathers with one
-// 16-byte load per node.  A permutation array maps internal slots to the caller's particle
-// order so that a later cell-sorted layout changes nothing at the ABI.
+// Particles are kept binned by 4x4x4-cell grid block (counting sort every `resort_interval`
+// substeps, all on the device).  One workgroup serves <= 256 particles of one block: it stages the
+// block's 8x8x8 node neighbourhood of grid velocities in LDS (one coalesced pass), every particle
+// gathers its 27 nodes from LDS, scatters its 27 x (m*v, m) contributions with LDS float atomics
+// (ds_add_f32) into a second LDS tile, and the workgroup flushes the tile's non-zero nodes to HBM with
+// one global fp32 atomic per word: ~2k global atomics per workgroup instead of 27.6k.  A particle whose
+// stencil has drifted out of its workgroup's tile (stale binning) takes a slow path straight to
+// global memory, so correctness never depends on the binning being fresh.
+//
+// Layout in HBM: particle state is SoA fp32/int32 rows of one [45][n] word array (each row a fully
+// coalesced 256 B/wave stream; two copies, ping-ponged by the re-binning permutation); the grid is two
+// float4 arrays: gin = (m*v.xyz, m) that P2G accumulates, gout = (v.xyz, 0) that G2P gathers.  `perm`
+// maps internal slots to the caller's particle order; every import/export goes through it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -30,14 +40,27 @@
 
 namespace pixie {
 
+constexpr int kBS = 4;                    // cells per block edge (particles are binned by the block of their stencil base)
+constexpr int kTS = 8;                    // tile nodes per edge: kBS + 2 (stencil reach) + 2 (one-cell drift margin each side)
+constexpr int kTN = kTS * kTS * kTS;      // 512 nodes
+constexpr int kWG = 256;                  // particles per work item / threads per workgroup
+
+// rows of the particle word array
+enum Row {
+    R_X = 0, R_V = 3, R_F = 6, R_FT = 15, R_C = 24, R_VOL = 33, R_MASS, R_DENSITY, R_E, R_NU, R_MU, R_LAM, R_BULK, R_YS,
+    R_MATERIAL, R_SELECTION, R_PERM, R_COUNT
+};
+static_assert(R_COUNT == 45, "row table");
+
 struct MpmPtrs {
-    int n, ng;
+    int n, ng, nbk;   // particles, grid nodes per axis, blocks per axis
     float dx, inv_dx;
     float *x, *v, *F, *Ft, *C;  // SoA: [3][n], [3][n], [9][n], [9][n], [9][n]
     float *vol, *mass, *density, *E, *nu, *mu, *lam, *bulk, *ys;
-    int *material, *selection;
+    int *material, *selection, *perm;
     float4 *gin, *gout;
-    unsigned long long* oob;
+    const int4* items;           // work list: (block id, first slot, count, 0)
+    unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles
 };
 
 struct StepParams {
@@ -64,7 +87,7 @@ struct PModDev {
     int type;
     float point[3], force[3], velocity[3], normal[3], h1[3], h2[3];
     float rot_scale, trans_scale, start, end;
-    const int* mask;
+    const int* mask;   // [n] in the CALLER's particle order (index through perm)
 };
 constexpr int kMaxPModFused = 8;
 struct PModSet {
@@ -74,10 +97,10 @@ struct PModSet {
 
 // ------------------------------------------------------------------ particle modifiers
 // apply_force (mpm_solver_warp.py:1015-1027), modify_particle_v_before_p2g (:1061-1073, :1137-1179)
-__device__ __forceinline__ void apply_pmod(const PModDev& m, int slot, float time, float dt, float mass,
+__device__ __forceinline__ void apply_pmod(const PModDev& m, int caller_idx, float time, float dt, float mass,
                                            const float x[3], float v[3]) {
     if (!(time >= m.start && time < m.end)) return;
-    if (m.mask[slot] != 1) return;
+    if (m.mask[caller_idx] != 1) return;
     if (m.type == PIXIE_PM_IMPULSE) {
         for (int d = 0; d < 3; ++d) v[d] = v[d] + (m.force[d] / mass) * dt;
     } else if (m.type == PIXIE_PM_TRANSLATION) {
@@ -102,18 +125,170 @@ __device__ __forceinline__ bool stencil_inside(const Stencil& st, int ng) {
     return ok;
 }
 
-// ------------------------------------------------------------------ fused particle kernel
+// ------------------------------------------------------------------ separable transfer cores
+// The 27-node sums of g2p (mpm_utils.py:436-455) and p2g_apic_with_stress (:360-393) are tensor products of
+// 1-D quadratic B-spline weights, so they are evaluated axis by axis (z innermost): 9 FMAs per node
+// instead of ~28.  This only re-associates the reference's fp32 sums.
+struct Weights1D {
+    float w[3], dw[3], wd[3];  // weight, derivative (cell units), weight * (offset - fx)
+};
+__device__ __forceinline__ void weights_1d(const Stencil& st, int d, Weights1D& o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o.w[i] = st.w[d][i];
+        o.dw[i] = st.dw[d][i];
+        o.wd[i] = st.w[d][i] * ((float)i - st.fx[d]);
+    }
+}
+
+// v = sum w g;  B_ab = sum w g_a dpos_b (cell units);  G_ab = sum g_a dweight_b (cell units)
+template <class Fetch>
+__device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float nv[3], Mat3& B, Mat3& G) {
+    Weights1D wx, wy, wz;
+    weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) nv[a] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { B.m[q] = 0.0f; G.m[q] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float ss[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, ys[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, sz[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s[3] = {0, 0, 0}, d[3] = {0, 0, 0}, z[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float g[3];
+                fetch(i, j, k, g);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = fmaf(wz.w[k], g[a], s[a]);
+                    d[a] = fmaf(wz.dw[k], g[a], d[a]);
+                    z[a] = fmaf(wz.wd[k], g[a], z[a]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                ss[a] = fmaf(wy.w[j], s[a], ss[a]);
+                ds[a] = fmaf(wy.dw[j], s[a], ds[a]);
+                ys[a] = fmaf(wy.wd[j], s[a], ys[a]);
+                sd[a] = fmaf(wy.w[j], d[a], sd[a]);
+                sz[a] = fmaf(wy.w[j], z[a], sz[a]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            nv[a] = fmaf(wx.w[i], ss[a], nv[a]);
+            G.m[3 * a + 0] = fmaf(wx.dw[i], ss[a], G.m[3 * a + 0]);
+            B.m[3 * a + 0] = fmaf(wx.wd[i], ss[a], B.m[3 * a + 0]);
+            G.m[3 * a + 1] = fmaf(wx.w[i], ds[a], G.m[3 * a + 1]);
+            B.m[3 * a + 1] = fmaf(wx.w[i], ys[a], B.m[3 * a + 1]);
+            G.m[3 * a + 2] = fmaf(wx.w[i], sd[a], G.m[3 * a + 2]);
+            B.m[3 * a + 2] = fmaf(wx.w[i], sz[a], B.m[3 * a + 2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the 27 loads of the next x-slab from being hoisted over this one
+    }
+}
+
+// momentum_a(i,j,k) = w (mv_a + A_a . dpos) + T_a . gradw,  mass(i,j,k) = w m   with A = m C' dx (dpos in cell
+// units) and T = -dt vol inv_dx tau (gradw in cell units)
+template <class Emit>
+__device__ __forceinline__ void p2g_scatter(const Stencil& st, const float mv[3], const Mat3& A, const Mat3& T, float mass, Emit emit) {
+    Weights1D wx, wy, wz;
+    weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float e[3], tx[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            e[a] = fmaf(A.m[3 * a + 0], wx.wd[i], wx.w[i] * mv[a]);  // wx (mv + A_a0 dpx)
+            tx[a] = T.m[3 * a + 0] * wx.dw[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float wij = wx.w[i] * wy.w[j];
+            const float widj = wx.w[i] * wy.dw[j];
+            const float wijd = wx.w[i] * wy.wd[j];
+            float P[3], Q[3], R[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                P[a] = fmaf(e[a], wy.w[j], fmaf(A.m[3 * a + 1], wijd, fmaf(tx[a], wy.w[j], T.m[3 * a + 1] * widj)));
+                Q[a] = wij * A.m[3 * a + 2];
+                R[a] = wij * T.m[3 * a + 2];
+            }
+            const float M = wij * mass;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float mom[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) mom[a] = fmaf(wz.w[k], P[a], fmaf(wz.wd[k], Q[a], wz.dw[k] * R[a]));
+                emit(i, j, k, mom, wz.w[k] * M);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- slow path: a particle whose stencil lies outside its workgroup's tile talks to HBM directly.  Rare
+// (stale binning only), so it is kept out of line and rolled to stay out of the fast path's register budget.
+__device__ __noinline__ void g2p_gather_global(const float4* __restrict__ gout, int ng, Stencil st, float* nv9 /* nv[3], B[9], G[9] */) {
+    float nv[3] = {0, 0, 0}, B[9], G[9];
+    for (int q = 0; q < 9; ++q) { B[q] = 0.0f; G[q] = 0.0f; }
+    const size_t r0 = ((size_t)st.base[0] * ng + st.base[1]) * ng + st.base[2];
+#pragma unroll 1
+    for (int t = 0; t < 27; ++t) {
+        const int i = t / 9, j = (t / 3) % 3, k = t % 3;
+        const float4 q = gout[r0 + ((size_t)i * ng + j) * ng + k];
+        const float g[3] = {q.x, q.y, q.z};
+        const float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
+        const float gw[3] = {st.dw[0][i] * st.w[1][j] * st.w[2][k], st.w[0][i] * st.dw[1][j] * st.w[2][k],
+                             st.w[0][i] * st.w[1][j] * st.dw[2][k]};
+        const float dp[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)k - st.fx[2]};
+        for (int a = 0; a < 3; ++a) {
+            nv[a] += w * g[a];
+            for (int b = 0; b < 3; ++b) {
+                B[3 * a + b] += w * g[a] * dp[b];
+                G[3 * a + b] += g[a] * gw[b];
+            }
+        }
+    }
+    for (int a = 0; a < 3; ++a) nv9[a] = nv[a];
+    for (int q = 0; q < 9; ++q) { nv9[3 + q] = B[q]; nv9[12 + q] = G[q]; }
+}
+
+__device__ __noinline__ void p2g_scatter_global(float4* gin, int ng, Stencil st, const float* mvAT /* mv[3], A[9], T[9] */, float mass) {
+    const size_t r0 = ((size_t)st.base[0] * ng + st.base[1]) * ng + st.base[2];
+#pragma unroll 1
+    for (int t = 0; t < 27; ++t) {
+        const int i = t / 9, j = (t / 3) % 3, k = t % 3;
+        const float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
+        const float gw[3] = {st.dw[0][i] * st.w[1][j] * st.w[2][k], st.w[0][i] * st.dw[1][j] * st.w[2][k],
+                             st.w[0][i] * st.w[1][j] * st.dw[2][k]};
+        const float dp[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)k - st.fx[2]};
+        float* cell = reinterpret_cast<float*>(gin + r0 + ((size_t)i * ng + j) * ng + k);
+        for (int a = 0; a < 3; ++a) {
+            const float* A = mvAT + 3 + 3 * a;
+            const float* T = mvAT + 12 + 3 * a;
+            const float mom = w * (mvAT[a] + A[0] * dp[0] + A[1] * dp[1] + A[2] * dp[2]) + T[0] * gw[0] + T[1] * gw[1] + T[2] * gw[2];
+            unsafeAtomicAdd(cell + a, mom);
+        }
+        unsafeAtomicAdd(cell + 3, w * mass);
+    }
+}
+
+// ------------------------------------------------------------------ fused block kernel
 // G2P part: g2p (mpm_utils.py:412-463).  P2G part: pre-P2G modifiers, compute_stress_from_F_trial
 // (:467-526) and p2g_apic_with_stress (:338-394).  `sp.time` is the time of the substep whose P2G runs.
-template <bool DO_G2P, bool DO_P2G>
-__global__ __launch_bounds__(256) void mpm_particle_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= S.n) return;
+template <bool DO_G2P, bool DO_P2G, int DBG>
+__device__ __forceinline__ void particle_body(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
+                                              int oz, float (*tv)[kTN], float (*ta)[kTN]) {
     if (S.selection[p] != 0) return;
     const int n = S.n;
     float x[3], v[3];
     Mat3 C, Ft;
+#pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = S.x[d * n + p];
+    bool slow = false;
 
     if (DO_G2P) {
         const Stencil st = make_stencil(x[0], x[1], x[2], S.inv_dx);
@@ -121,57 +296,56 @@ __global__ __launch_bounds__(256) void mpm_particle_kernel(MpmPtrs S, StepParams
             atomicAdd(S.oob, 1ull);
             return;
         }
-        float nv[3] = {0.0f, 0.0f, 0.0f};
-        Mat3 nC, gv;
-        for (int i = 0; i < 9; ++i) { nC.m[i] = 0.0f; gv.m[i] = 0.0f; }
+        Mat3 Fold;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float wij = st.w[0][i] * st.w[1][j];
-                const float dwi_wj = st.dw[0][i] * st.w[1][j];
-                const float wi_dwj = st.w[0][i] * st.dw[1][j];
-                const size_t row = ((size_t)(st.base[0] + i) * S.ng + (st.base[1] + j)) * S.ng + st.base[2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float4 g = S.gout[row + k];
-                    const float w = wij * st.w[2][k];
-                    const float dwx = dwi_wj * st.w[2][k] * S.inv_dx;
-                    const float dwy = wi_dwj * st.w[2][k] * S.inv_dx;
-                    const float dwz = wij * st.dw[2][k] * S.inv_dx;
-                    const float dp[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)k - st.fx[2]};
-                    const float gvv[3] = {g.x, g.y, g.z};
-                    const float sc = w * S.inv_dx * 4.0f;
-                    for (int a = 0; a < 3; ++a) {
-                        nv[a] += gvv[a] * w;
-                        for (int b = 0; b < 3; ++b) nC.m[3 * a + b] += (gvv[a] * dp[b]) * sc;
-                        gv.m[3 * a + 0] += gvv[a] * dwx;
-                        gv.m[3 * a + 1] += gvv[a] * dwy;
-                        gv.m[3 * a + 2] += gvv[a] * dwz;
-                    }
-                }
-            }
-        }
-        Mat3 Fold, A;
         for (int i = 0; i < 9; ++i) Fold.m[i] = S.F[i * n + p];
-        for (int i = 0; i < 9; ++i) A.m[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + gv.m[i] * sp.dt;
-        Ft = mat_mul(A, Fold);
-        C = nC;
+        float nv[3];
+        Mat3 B, G;
+        const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
+        if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
+            const int b0 = (lx * kTS + ly) * kTS + lz;
+            g2p_gather(st, [&](int i, int j, int k, float g[3]) {
+                const int idx = b0 + (i * kTS + j) * kTS + k;
+                g[0] = tv[0][idx]; g[1] = tv[1][idx]; g[2] = tv[2][idx];
+            }, nv, B, G);
+        } else {
+            slow = true;
+            float acc[21];
+            g2p_gather_global(S.gout, S.ng, st, acc);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) nv[a] = acc[a];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { B.m[q] = acc[3 + q]; G.m[q] = acc[12 + q]; }
+        }
+        Mat3 Amat;
+        const float sdt = sp.dt * S.inv_dx;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Amat.m[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + G.m[i] * sdt;
+        Ft = mat_mul(Amat, Fold);
+        const float sc = 4.0f * S.inv_dx;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) C.m[i] = B.m[i] * sc;
+#pragma unroll
         for (int d = 0; d < 3; ++d) {
             v[d] = nv[d];
             x[d] = x[d] + sp.dt * nv[d];
             S.x[d * n + p] = x[d];
         }
-        for (int i = 0; i < 9; ++i) {
-            S.C[i * n + p] = C.m[i];
-            S.Ft[i * n + p] = Ft.m[i];
-        }
-        if (!DO_P2G) {
+        if (!DO_P2G) {  // the state a caller can observe: x, v, C, F_trial
+#pragma unroll
             for (int d = 0; d < 3; ++d) S.v[d * n + p] = v[d];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                S.C[i * n + p] = C.m[i];
+                S.Ft[i * n + p] = Ft.m[i];
+            }
+            if (slow) atomicAdd(S.oob + 1, 1ull);
             return;
         }
     } else {
+#pragma unroll
         for (int d = 0; d < 3; ++d) v[d] = S.v[d * n + p];
+#pragma unroll
         for (int i = 0; i < 9; ++i) {
             C.m[i] = S.C[i * n + p];
             Ft.m[i] = S.Ft[i * n + p];
@@ -180,16 +354,22 @@ __global__ __launch_bounds__(256) void mpm_particle_kernel(MpmPtrs S, StepParams
 
     if (DO_P2G) {
         const float mass = S.mass[p];
-        const float v_before[3] = {v[0], v[1], v[2]};
-        for (int k = 0; k < pms.n; ++k) apply_pmod(pms.pm[k], p, sp.time, sp.dt, mass, x, v);
-        if (DO_G2P || v[0] != v_before[0] || v[1] != v_before[1] || v[2] != v_before[2])
-            for (int d = 0; d < 3; ++d) S.v[d * n + p] = v[d];
-
+        if (pms.n > 0) {
+            const float v_before[3] = {v[0], v[1], v[2]};
+            const int ci = S.perm[p];
+            for (int k = 0; k < pms.n; ++k) apply_pmod(pms.pm[k], ci, sp.time, sp.dt, mass, x, v);
+            if (!DO_G2P && (v[0] != v_before[0] || v[1] != v_before[1] || v[2] != v_before[2]))
+                for (int d = 0; d < 3; ++d) S.v[d * n + p] = v[d];
+        }
         const int material = S.material[p];
-        float mu = S.mu[p], lam = S.lam[p], ys = S.ys[p];
+        float mu = S.mu[p], lam = S.lam[p];
+        float ys = (material == 1 || material == 3 || material == 5) ? S.ys[p] : 0.0f;
+        const float bulk = (material == 6) ? S.bulk[p] : 0.0f;
         const float mu0 = mu, lam0 = lam, ys0 = ys;
         Mat3 F, tau;
-        return_map_and_stress(material, Ft, mu, lam, S.bulk[p], ys, sp.ms, sp.dt, F, tau);
+        if (DBG == 3) { F = Ft; for (int i = 0; i < 9; ++i) tau.m[i] = 0.0f; }
+        else return_map_and_stress(material, Ft, mu, lam, bulk, ys, sp.ms, sp.dt, F, tau);
+#pragma unroll
         for (int i = 0; i < 9; ++i) S.F[i * n + p] = F.m[i];
         if (ys != ys0) S.ys[p] = ys;
         if (mu != mu0) S.mu[p] = mu;
@@ -201,45 +381,164 @@ __global__ __launch_bounds__(256) void mpm_particle_kernel(MpmPtrs S, StepParams
             return;
         }
         // C' = (1-r) C + r/2 (C - C^T);  r < -0.001 => PIC (mpm_utils.py:372-379)
-        Mat3 A;  // mass * C'
+        Mat3 A;  // mass * C' * dx   (dpos = (ijk - fx) * dx)
+#pragma unroll
         for (int a = 0; a < 3; ++a)
+#pragma unroll
             for (int b = 0; b < 3; ++b) {
                 float c = (1.0f - sp.rpic) * C.m[3 * a + b] + sp.rpic * 0.5f * (C.m[3 * a + b] - C.m[3 * b + a]);
                 if (sp.rpic < -0.001f) c = 0.0f;
-                A.m[3 * a + b] = mass * c * S.dx;  // dpos = (ijk - fx) * dx
+                A.m[3 * a + b] = mass * c * S.dx;
             }
         const float mv[3] = {mass * v[0], mass * v[1], mass * v[2]};
         const float ks = -sp.dt * S.vol[p] * S.inv_dx;  // dt * (-vol * tau * dweight), dweight = dw*w*w*inv_dx
         Mat3 T;
+#pragma unroll
         for (int i = 0; i < 9; ++i) T.m[i] = ks * tau.m[i];
+        const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
+        if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
+            const int b0 = (lx * kTS + ly) * kTS + lz;
+            if (DBG != 2) p2g_scatter(st, mv, A, T, mass, [&](int i, int j, int k, const float mom[3], float m) {
+                const int idx = b0 + (i * kTS + j) * kTS + k;
+                atomicAdd(&ta[0][idx], mom[0]);
+                atomicAdd(&ta[1][idx], mom[1]);
+                atomicAdd(&ta[2][idx], mom[2]);
+                atomicAdd(&ta[3][idx], m);
+            });
+        } else {
+            slow = true;
+            float mvAT[21];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+            for (int a = 0; a < 3; ++a) mvAT[a] = mv[a];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float wij = st.w[0][i] * st.w[1][j];
-                const float dwi_wj = st.dw[0][i] * st.w[1][j];
-                const float wi_dwj = st.w[0][i] * st.dw[1][j];
-                const size_t row = ((size_t)(st.base[0] + i) * S.ng + (st.base[1] + j)) * S.ng + st.base[2];
+            for (int q = 0; q < 9; ++q) { mvAT[3 + q] = A.m[q]; mvAT[12 + q] = T.m[q]; }
+            p2g_scatter_global(S.gin, S.ng, st, mvAT, mass);
+        }
+        if (slow) atomicAdd(S.oob + 1, 1ull);
+    }
+}
+
+template <bool DO_G2P, bool DO_P2G, int DBG = 0>
+__global__ __launch_bounds__(kWG) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
+    __shared__ float tv[3][kTN];  // grid velocities of the tile (G2P source)
+    __shared__ float ta[4][kTN];  // (m*v.xyz, m) accumulated by this workgroup (P2G target)
+    const int4 it = S.items[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
+    const int ox = bx * kBS - 1, oy = by * kBS - 1, oz = bz * kBS - 1;
+    const int ng = S.ng;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float w = wij * st.w[2][k];
-                    const float gw[3] = {dwi_wj * st.w[2][k], wi_dwj * st.w[2][k], wij * st.dw[2][k]};
-                    const float dp[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)k - st.fx[2]};
-                    float mom[3];
-                    for (int a = 0; a < 3; ++a) {
-                        const float aff = A.m[3 * a] * dp[0] + A.m[3 * a + 1] * dp[1] + A.m[3 * a + 2] * dp[2];
-                        const float frc = T.m[3 * a] * gw[0] + T.m[3 * a + 1] * gw[1] + T.m[3 * a + 2] * gw[2];
-                        mom[a] = w * (mv[a] + aff) + frc;
-                    }
-                    float* cell = reinterpret_cast<float*>(S.gin + row + k);
-                    unsafeAtomicAdd(cell + 0, mom[0]);
-                    unsafeAtomicAdd(cell + 1, mom[1]);
-                    unsafeAtomicAdd(cell + 2, mom[2]);
-                    unsafeAtomicAdd(cell + 3, w * mass);
-                }
+    for (int idx = tid; idx < kTN; idx += kWG) {
+        if (DO_G2P) {
+            const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng)
+                g = S.gout[((size_t)gx * ng + gy) * ng + gz];
+            tv[0][idx] = g.x; tv[1][idx] = g.y; tv[2][idx] = g.z;
+        }
+        if (DO_P2G) { ta[0][idx] = 0.f; ta[1][idx] = 0.f; ta[2][idx] = 0.f; ta[3][idx] = 0.f; }
+    }
+    __syncthreads();
+    for (int q = tid; q < it.z; q += kWG) particle_body<DO_G2P, DO_P2G, DBG>(S, sp, pms, it.y + q, ox, oy, oz, tv, ta);
+    if (DO_P2G && DBG != 1 && DBG != 2) {
+        __syncthreads();
+#pragma unroll
+        for (int idx = tid; idx < kTN; idx += kWG) {
+            const float mx = ta[0][idx], my = ta[1][idx], mz = ta[2][idx], m = ta[3][idx];
+            if (mx != 0.f || my != 0.f || mz != 0.f || m != 0.f) {
+                const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
+                float* cell = reinterpret_cast<float*>(S.gin + ((size_t)gx * ng + gy) * ng + gz);
+                unsafeAtomicAdd(cell + 0, mx);
+                unsafeAtomicAdd(cell + 1, my);
+                unsafeAtomicAdd(cell + 2, mz);
+                unsafeAtomicAdd(cell + 3, m);
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ re-binning (counting sort by block)
+__device__ __forceinline__ int block_of(const MpmPtrs& S, int p) {
+    int b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int base = (int)(S.x[d * S.n + p] * S.inv_dx - 0.5f);
+        base = max(0, min(base, S.ng - 3));
+        b[d] = base / kBS;
+    }
+    return (b[0] * S.nbk + b[1]) * S.nbk + b[2];
+}
+
+// key[p] = block of particle p; rank[p] = its arrival number inside the block.  Lanes of a wave that share a key
+// (the common case once the particles are binned) issue one atomic for the whole group.
+__global__ __launch_bounds__(256) void bin_count_kernel(MpmPtrs S, int* __restrict__ keys, int* __restrict__ rank,
+                                                        int* __restrict__ counts) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < S.n;
+    const int key = valid ? block_of(S, p) : -1;
+    const int lane = threadIdx.x & 63;
+    int my_rank = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long grp = __ballot(valid && key == k) & todo;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counts[k], __popcll(grp));
+        base = __shfl(base, leader);
+        if (valid && key == k && ((grp >> lane) & 1ull)) my_rank = base + __popcll(grp & ((1ull << lane) - 1ull));
+        todo &= ~grp;
+    }
+    if (valid) { keys[p] = key; rank[p] = my_rank; }
+}
+
+// exclusive scan of the block counts + the work list (<= kWG particles per item), one workgroup
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets,
+                                                        int4* __restrict__ items, int* __restrict__ n_items, int nblocks, int cap) {
+    __shared__ int s_cnt[1024], s_itm[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    int csum = 0, isum = 0;
+    for (int b = b0; b < b1; ++b) { const int c = counts[b]; csum += c; isum += (c + cap - 1) / cap; }
+    s_cnt[tid] = csum; s_itm[tid] = isum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int a = 0, b = 0;
+        if (tid >= off) { a = s_cnt[tid - off]; b = s_itm[tid - off]; }
+        __syncthreads();
+        s_cnt[tid] += a; s_itm[tid] += b;
+        __syncthreads();
+    }
+    int c = s_cnt[tid] - csum, i = s_itm[tid] - isum;  // exclusive prefixes
+    for (int b = b0; b < b1; ++b) {
+        const int cnt = counts[b];
+        offsets[b] = c;
+        for (int j = 0; j < cnt; j += cap) items[i++] = make_int4(b, c + j, min(cap, cnt - j), 0);
+        c += cnt;
+    }
+    if (tid == 1023) *n_items = s_itm[1023];
+}
+
+__global__ __launch_bounds__(256) void bin_order_kernel(const int* __restrict__ keys, const int* __restrict__ rank,
+                                                        const int* __restrict__ offsets, int* __restrict__ order, int n) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n) order[offsets[keys[p]] + rank[p]] = p;
+}
+
+// dst[r][q] = src[r][order[q]] for every row of the particle word array
+__global__ __launch_bounds__(256) void bin_permute_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                          const int* __restrict__ order, int n, int rows_per_y) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const int p = order[q];
+    const int r0 = blockIdx.y * rows_per_y, r1 = min(r0 + rows_per_y, (int)R_COUNT);
+    for (int r = r0; r < r1; ++r) dst[(size_t)r * n + q] = src[(size_t)r * n + p];
+}
+
+__global__ void iota_kernel(int* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i;
 }
 
 // ------------------------------------------------------------------ grid kernel
@@ -320,7 +619,7 @@ __global__ void pmod_kernel(MpmPtrs S, StepParams sp, PModDev m) {  // overflow 
     if (p >= S.n) return;
     float x[3], v[3];
     for (int d = 0; d < 3; ++d) { x[d] = S.x[d * S.n + p]; v[d] = S.v[d * S.n + p]; }
-    apply_pmod(m, p, sp.time, sp.dt, S.mass[p], x, v);
+    apply_pmod(m, S.perm[p], sp.time, sp.dt, S.mass[p], x, v);
     for (int d = 0; d < 3; ++d) S.v[d * S.n + p] = v[d];
 }
 
@@ -385,7 +684,7 @@ __global__ void select_kernel(MpmPtrs S, PModDev m, float3 size, float half_heig
     } else {
         sel = (fabsf(o[0]) < size.x && fabsf(o[1]) < size.y && fabsf(o[2]) < size.z) ? 1 : 0;
     }
-    mask[i] = sel;
+    mask[S.perm[i]] = sel;  // masks are kept in the caller's order
 }
 // compute_cov_from_F, mpm_utils.py:529-553
 __global__ void cov_kernel(MpmPtrs S, const float* __restrict__ init_cov, float* __restrict__ cov, const int* perm) {
@@ -452,7 +751,20 @@ struct pixie_mpm {
     std::vector<PModDev> pmods;
     std::vector<int*> masks;
     float* init_cov = nullptr;               // [n][6], caller order
-    int* perm = nullptr;                     // internal slot -> caller index (nullptr = identity)
+    // particle word array [R_COUNT][n], two copies ping-ponged by the re-binning permutation
+    unsigned* words[2] = {nullptr, nullptr};
+    int cur = 0;
+    // re-binning scratch
+    int nblocks = 0;
+    int *keys = nullptr, *rank = nullptr, *counts = nullptr, *offsets = nullptr, *order = nullptr, *d_n_items = nullptr;
+    int4* items = nullptr;
+    int* h_n_items = nullptr;                // pinned
+    int n_items = 0;
+    bool needs_sort = true;                  // positions changed behind the binning's back (or never binned)
+    int resort_interval = 32, steps_since_sort = 0;
+    int item_cap = kWG;                      // particles per work item (multiple of kWG; one flush per item)
+    int debug_variant = 0;
+    long n_sorts = 0;
     std::vector<void*> allocs;
     bool dirty_grid = false;                 // gin holds an un-consumed P2G (phase API)
     // profiling
@@ -469,6 +781,43 @@ int dev_alloc(pixie_mpm* h, T** ptr, size_t count) {
     PX_CHECK_HIP(hipMemset(p, 0, count * sizeof(T)));
     h->allocs.push_back(p);
     *ptr = static_cast<T*>(p);
+    return 0;
+}
+
+// point the row pointers of h->S at the current copy of the word array
+void bind_rows(pixie_mpm* h) {
+    MpmPtrs& S = h->S;
+    const size_t n = (size_t)S.n;
+    float* f = reinterpret_cast<float*>(h->words[h->cur]);
+    int* i = reinterpret_cast<int*>(h->words[h->cur]);
+    S.x = f + R_X * n; S.v = f + R_V * n; S.F = f + R_F * n; S.Ft = f + R_FT * n; S.C = f + R_C * n;
+    S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
+    S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
+    S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n;
+    S.items = h->items;
+}
+
+// Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
+// the host only waits for the 4-byte item count so that the block kernel gets an exact grid.
+int rebin(pixie_mpm* h, hipStream_t st) {
+    MpmPtrs& S = h->S;
+    const int n = S.n;
+    PX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->nblocks * sizeof(int), st));
+    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->d_n_items, h->nblocks, h->item_cap);
+    hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
+    const int rows_per_y = 9;
+    hipLaunchKernelGGL(bin_permute_kernel, dim3(cdiv(n, 256), cdiv(R_COUNT, rows_per_y)), dim3(256), 0, st,
+                       h->words[h->cur], h->words[h->cur ^ 1], h->order, n, rows_per_y);
+    PX_CHECK_HIP(hipGetLastError());
+    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, sizeof(int), hipMemcpyDeviceToHost, st));
+    PX_CHECK_HIP(hipStreamSynchronize(st));
+    h->n_items = *h->h_n_items;
+    h->cur ^= 1;
+    bind_rows(h);
+    h->needs_sort = false;
+    h->steps_since_sort = 0;
+    ++h->n_sorts;
     return 0;
 }
 
@@ -513,35 +862,46 @@ bool find_field(pixie_mpm* h, const std::string& name, FieldInfo* fi) {
 }
 
 int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st) {
+    if (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval))
+        if (rebin(h, st)) return 1;
+    if (g2p) ++h->steps_since_sort;
     const int blocks = cdiv(h->S.n, 256);
+    const dim3 grid((unsigned)std::max(h->n_items, 1));
     PModSet pms{};
     // impulses first, then velocity modifiers (mpm_solver_warp.py:529-547)
     std::vector<PModDev> ordered;
     for (const PModDev& m : h->pmods) if (m.type == PIXIE_PM_IMPULSE) ordered.push_back(m);
     for (const PModDev& m : h->pmods) if (m.type != PIXIE_PM_IMPULSE) ordered.push_back(m);
+    // modifiers whose time window cannot contain this substep are dropped on the host
+    ordered.erase(std::remove_if(ordered.begin(), ordered.end(),
+                                 [&](const PModDev& m) { return !(sp.time >= m.start && sp.time < m.end); }), ordered.end());
     const bool fused_mods = ordered.size() <= (size_t)kMaxPModFused;
     if (fused_mods) {
         pms.n = (int)ordered.size();
         for (int k = 0; k < pms.n; ++k) pms.pm[k] = ordered[k];
     }
+    if (h->n_items == 0) return 0;  // no particles binned (n_particles > 0 always gives >= 1 item)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile && p2g && g2p) {
         PX_CHECK_HIP(hipEventCreate(&e0)); PX_CHECK_HIP(hipEventCreate(&e1));
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        hipLaunchKernelGGL((mpm_particle_kernel<true, true>), dim3(blocks), dim3(256), 0, st, h->S, sp, pms);
+        if (h->debug_variant == 1) hipLaunchKernelGGL((mpm_block_kernel<true, true, 1>), grid, dim3(kWG), 0, st, h->S, sp, pms);
+        else if (h->debug_variant == 2) hipLaunchKernelGGL((mpm_block_kernel<true, true, 2>), grid, dim3(kWG), 0, st, h->S, sp, pms);
+        else if (h->debug_variant == 3) hipLaunchKernelGGL((mpm_block_kernel<true, true, 3>), grid, dim3(kWG), 0, st, h->S, sp, pms);
+        else hipLaunchKernelGGL((mpm_block_kernel<true, true>), grid, dim3(kWG), 0, st, h->S, sp, pms);
     } else {
         if (g2p) {
             PModSet none{};
-            hipLaunchKernelGGL((mpm_particle_kernel<true, false>), dim3(blocks), dim3(256), 0, st, h->S, sp, none);
+            hipLaunchKernelGGL((mpm_block_kernel<true, false>), grid, dim3(kWG), 0, st, h->S, sp, none);
         }
         if (p2g) {
             if (!fused_mods) {
                 for (const PModDev& m : ordered)
                     hipLaunchKernelGGL(pmod_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, m);
             }
-            hipLaunchKernelGGL((mpm_particle_kernel<false, true>), dim3(blocks), dim3(256), 0, st, h->S, sp, pms);
+            hipLaunchKernelGGL((mpm_block_kernel<false, true>), grid, dim3(kWG), 0, st, h->S, sp, pms);
         }
     }
     if (e0) {
@@ -606,16 +966,20 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     S.inv_dx = (float)((double)n_grid / grid_lim);
     const size_t n = (size_t)n_particles, G = (size_t)n_grid * n_grid * n_grid;
     int rc = 0;
-    rc |= dev_alloc(h, &S.x, 3 * n); rc |= dev_alloc(h, &S.v, 3 * n);
-    rc |= dev_alloc(h, &S.F, 9 * n); rc |= dev_alloc(h, &S.Ft, 9 * n); rc |= dev_alloc(h, &S.C, 9 * n);
-    rc |= dev_alloc(h, &S.vol, n); rc |= dev_alloc(h, &S.mass, n); rc |= dev_alloc(h, &S.density, n);
-    rc |= dev_alloc(h, &S.E, n); rc |= dev_alloc(h, &S.nu, n); rc |= dev_alloc(h, &S.mu, n); rc |= dev_alloc(h, &S.lam, n);
-    rc |= dev_alloc(h, &S.bulk, n); rc |= dev_alloc(h, &S.ys, n);
-    rc |= dev_alloc(h, &S.material, n); rc |= dev_alloc(h, &S.selection, n);
+    S.nbk = (n_grid + kBS - 1) / kBS;
+    h->nblocks = S.nbk * S.nbk * S.nbk;
+    const size_t max_items = (n + kWG - 1) / kWG + std::min<size_t>((size_t)h->nblocks, n);
+    rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
     rc |= dev_alloc(h, &S.gin, G); rc |= dev_alloc(h, &S.gout, G);
-    rc |= dev_alloc(h, &S.oob, 1);
+    rc |= dev_alloc(h, &S.oob, 2);
+    rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n);
+    rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks);
+    rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 1);
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
+    if (hipHostMalloc((void**)&h->h_n_items, sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
+    bind_rows(h);
+    hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.perm, n_particles);
     hipLaunchKernelGGL(identity_F_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.Ft, n_particles);  // :272-277
     PX_CHECK_HIP(hipDeviceSynchronize());
     // defaults of initialize(), mpm_solver_warp.py:74-92
@@ -631,6 +995,7 @@ int pixie_mpm_destroy(pixie_mpm* h) {
     if (!h) return 0;
     for (void* p : h->allocs) (void)hipFree(p);
     for (int* m : h->masks) (void)hipFree(m);
+    if (h->h_n_items) (void)hipHostFree(h->h_n_items);
     for (auto& e : h->ev_particle) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : h->ev_grid) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
@@ -650,10 +1015,11 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     FieldInfo fi;
     PX_REQUIRE(find_field(h, nm, &fi), "set_field: unknown field '%s'", name);
     PX_REQUIRE(count == (int64_t)n * fi.k, "set_field(%s): expected %lld scalars, got %lld", name, (long long)n * fi.k, (long long)count);
+    if (nm == "x") h->needs_sort = true;  // positions replaced: the block binning is stale
     if (fi.is_int)
-        hipLaunchKernelGGL(aos_to_soa_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)d_src, (int*)fi.ptr, n, fi.k, h->perm);
+        hipLaunchKernelGGL(aos_to_soa_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)d_src, (int*)fi.ptr, n, fi.k, h->S.perm);
     else
-        hipLaunchKernelGGL(aos_to_soa_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)d_src, (float*)fi.ptr, n, fi.k, h->perm);
+        hipLaunchKernelGGL(aos_to_soa_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)d_src, (float*)fi.ptr, n, fi.k, h->S.perm);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -674,7 +1040,7 @@ int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t cou
     }
     if (nm == "stress") {
         PX_REQUIRE(count == (int64_t)n * 9, "get_field(stress): expected %lld scalars", (long long)n * 9);
-        hipLaunchKernelGGL(stress_export_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S, (float*)d_dst, h->perm);
+        hipLaunchKernelGGL(stress_export_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S, (float*)d_dst, h->S.perm);
         PX_CHECK_HIP(hipGetLastError());
         return 0;
     }
@@ -688,9 +1054,9 @@ int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t cou
     PX_REQUIRE(find_field(h, nm, &fi), "get_field: unknown field '%s'", name);
     PX_REQUIRE(count == (int64_t)n * fi.k, "get_field(%s): expected %lld scalars, got %lld", name, (long long)n * fi.k, (long long)count);
     if (fi.is_int)
-        hipLaunchKernelGGL(soa_to_aos_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)fi.ptr, (int*)d_dst, n, fi.k, h->perm);
+        hipLaunchKernelGGL(soa_to_aos_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)fi.ptr, (int*)d_dst, n, fi.k, h->S.perm);
     else
-        hipLaunchKernelGGL(soa_to_aos_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)fi.ptr, (float*)d_dst, n, fi.k, h->perm);
+        hipLaunchKernelGGL(soa_to_aos_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)fi.ptr, (float*)d_dst, n, fi.k, h->S.perm);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -725,6 +1091,9 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
+    else if (k == "item_cap") { h->item_cap = std::max(kWG, ((int)value / kWG) * kWG); h->needs_sort = true; }
+    else if (k == "debug_variant") h->debug_variant = (int)value;
+    else if (k == "resort_interval") h->resort_interval = (int)value;   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
     return 0;
 }
@@ -738,6 +1107,14 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "alpha") *value = h->ms.alpha;
     else if (k == "rpic_damping") *value = h->rpic;
     else if (k == "grid_v_damping_scale") *value = h->damping;
+    else if (k == "resort_interval") *value = h->resort_interval;
+    else if (k == "n_work_items") *value = h->n_items;
+    else if (k == "n_rebins") *value = (double)h->n_sorts;
+    else if (k == "slow_path_particles") {  // synchronises the device
+        unsigned long long v = 0;
+        PX_CHECK_HIP(hipMemcpy(&v, h->S.oob + 1, sizeof v, hipMemcpyDeviceToHost));
+        *value = (double)v;
+    }
     else return set_error("get_scalar: unknown key '%s'", key);
     return 0;
 }
@@ -834,14 +1211,14 @@ int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream) {
 
 int pixie_mpm_export_cov(pixie_mpm* h, float* d_cov, void* stream) {
     PX_REQUIRE(h && d_cov, "null argument");
-    hipLaunchKernelGGL(cov_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, h->init_cov, d_cov, h->perm);
+    hipLaunchKernelGGL(cov_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, h->init_cov, d_cov, h->S.perm);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int pixie_mpm_export_R(pixie_mpm* h, float* d_R, void* stream) {
     PX_REQUIRE(h && d_R, "null argument");
-    hipLaunchKernelGGL(rot_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, d_R, h->perm);
+    hipLaunchKernelGGL(rot_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, d_R, h->S.perm);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }

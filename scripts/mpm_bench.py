@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""MPM-only timing on the GPU box: us/substep, fused-kernel / grid-kernel durations (HIP events on the launch
+stream), work items, slow-path particles.  Usage: python scripts/mpm_bench.py N NGRID [SUBSTEPS] [RESORT]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pixie_amd.mpm_solver import MPM_Simulator_WARP  # noqa: E402
+from pixie_amd.synthetic import apply_scene, mpm_ball_scene  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]); ng = int(sys.argv[2])
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+    resort = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    sc = mpm_ball_scene(n, seed=0, n_grid=ng)
+    s = MPM_Simulator_WARP(10)
+    s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
+                                   n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
+    apply_scene(s, sc)
+    s._set_scalar("resort_interval", resort)
+    if os.environ.get("PIXIE_ITEM_CAP"):
+        s._set_scalar("item_cap", int(os.environ["PIXIE_ITEM_CAP"]))
+    dbg = int(os.environ.get("PIXIE_DEBUG_VARIANT", "0"))
+    s._set_scalar("debug_variant", dbg)
+    s.run(sc["dt"], 64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.run(sc["dt"], steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s.set_profile(True)
+    s.run(sc["dt"], 128)
+    torch.cuda.synchronize()
+    p_ms, g_ms, nl = s.kernel_times()
+    s.set_profile(False)
+    alg = 212.0 * n + 44.0 * ng ** 3
+    print(f"n={n} ng={ng} resort={resort} cap={os.environ.get('PIXIE_ITEM_CAP', 256)} dbg={dbg}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
+          f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
+          f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
+          f"rebins {int(s._get_scalar('n_rebins'))} slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "
+          f"finite {bool(torch.isfinite(s.get_field('x')).all())}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -98,10 +98,15 @@ def test_rollout_parity(hip_device, scenario, steps):
     disp_h, disp_o = x_h - sc["x"], o64.field("x") - sc["x"]
     drift_d = rel_l2(o32.field("x") - sc["x"], disp_o)
     assert rel_l2(disp_h, disp_o) < max(1e-4, 4 * drift_d)
-    for name, got in (("v", v_h), ("C", C_h)):
-        drift = rel_l2(o32.field(name), o64.field(name))
-        err = rel_l2(got, o64.field(name))
-        print(f"{scenario} {name}: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}")
+    # v and C are compared on the scale of the velocity field: C is a velocity gradient, so its natural unit is
+    # rms|v| / dx (in free fall C is ~0 and a norm-relative error would compare roundoff with roundoff).
+    n = x_h.shape[0]
+    v_rms = float(np.linalg.norm(o64.field("v")) / np.sqrt(n))
+    inv_dx = sc["n_grid"] / sc["grid_lim"]
+    for name, got, scale in (("v", v_h, v_rms), ("C", C_h, max(v_rms * inv_dx, float(np.linalg.norm(o64.field("C")) / np.sqrt(n))))):
+        drift = float(np.linalg.norm(o32.field(name).astype(np.float64) - o64.field(name)) / np.sqrt(n)) / scale
+        err = float(np.linalg.norm(got.astype(np.float64) - o64.field(name)) / np.sqrt(n)) / scale
+        print(f"{scenario} {name}: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  (scale {scale:.3e})")
         assert err < max(1e-4, 4 * drift)
     assert h.out_of_bounds == 0
 
@@ -148,10 +153,27 @@ def test_boundary_conditions_and_modifiers(hip_device):
     for s in (h, o):
         s.enforce_particle_velocity_rotation(point=[1.0, 1.0, 1.0], normal=[0.0, 0.0, 1.0], half_height_and_radius=[0.05, 0.2],
                                              rotation_scale=0.5, translation_scale=0.01, start_time=0.0, end_time=1.5e-3)
-    h.run(sc["dt"], 50); o.run(sc["dt"], 50)
+    o32 = make_oracle(sc, "f32")
+    o32.enforce_particle_velocity_rotation(point=[1.0, 1.0, 1.0], normal=[0.0, 0.0, 1.0], half_height_and_radius=[0.05, 0.2],
+                                           rotation_scale=0.5, translation_scale=0.01, start_time=0.0, end_time=1.5e-3)
+    # 30 substeps: every modifier and BC has been active, and the state is still well conditioned
+    h.run(sc["dt"], 30); o.run(sc["dt"], 30); o32.run(sc["dt"], 30)
     assert rel_l2(get(h, "x"), o.field("x")) < 1e-5
-    assert rel_l2(get(h, "v"), o.field("v")) < 1e-3
+    drift = rel_l2(o32.field("v"), o.field("v"))
+    err = rel_l2(get(h, "v"), o.field("v"))
+    print(f"bc test v @30: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}")
+    assert err < max(1e-3, 2 * drift)
     assert rel_l2(get(h, "F_trial").reshape(-1, 3, 3), o.field("F_trial")) < 1e-4
+    # 20 more: through the cuboid's end_time and its 15-substep "reset" window, which zeroes the whole grid
+    # (mpm_solver_warp.py:895-897); afterwards v restarts from roundoff-sized forces, so it is only required to be
+    # as close to the float64 oracle as the float32 oracle is.
+    h.run(sc["dt"], 20); o.run(sc["dt"], 20); o32.run(sc["dt"], 20)
+    assert rel_l2(get(h, "x"), o.field("x")) < 1e-5
+    assert rel_l2(get(h, "F_trial").reshape(-1, 3, 3), o.field("F_trial")) < 1e-4
+    drift = rel_l2(o32.field("v"), o.field("v"))
+    err = rel_l2(get(h, "v"), o.field("v"))
+    print(f"bc test v @50: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}")
+    assert err < max(1e-3, 2 * drift)
 
 
 def test_exports_cov_and_rotation(hip_device):
