@@ -145,17 +145,34 @@ typedef struct pixie_conv_desc {
     /* epilogue: out = conv + bias (+ residual) */
     const float* d_residual;                      /* [c_out][OD][OH][OW] or NULL; may alias d_out */
     float* d_out;                                 /* [c_out][OD][OH][OW] */
+    /* f16x3 path (conv3d_f16x3.hip): used instead of d_w when d_w16 != NULL.  Requires stride 1, c0 % 8 == 0 and
+     * (c0+c1) % 16 == 0.  The kernel scales the (prologue-transformed) input by a power of two chosen from
+     * a bound on its magnitude so that it sits just below the fp16 range before the hi/lo split:
+     *   - raw inputs (no prologue): d_in_amax0/1 point at the tensors' |x|max as float bits
+     *     (pixie_channel_stats / pixie_tensor_amax keep them on the device -- no host sync);
+     *   - normalised inputs: in_bound is a host-side bound on |prologue(x)| (sqrt(N)*max|gamma|+max|beta|). */
+    const void* d_w16;                            /* from pixie_conv_pack_weights_f16x2, or NULL */
+    const uint32_t* d_in_amax0; const uint32_t* d_in_amax1;
+    float in_bound;
 } pixie_conv_desc;
 
 /* Repack an nn.Conv3d / nn.Conv1d weight (c_out, c_in, k,k,k) into the kernel's
  * [tap][c_in][c_out_padded] layout; c_out_padded = pixie_conv_cout_padded(c_out). */
 int pixie_conv_cout_padded(int c_out);
 int pixie_conv_pack_weights(const float* d_w_oidhw, float* d_w_packed, int c_out, int c_in, int ksize, void* stream);
-/* F.conv3d / nn.Conv3d forward on the fp32 MFMA path. */
+/* The same weight, split into fp16 hi/lo halves (w*s = hi + lo, s a power of two chosen on the device from
+ * |w|max) and swizzled for the f16 MFMA A operand; d_packed needs pixie_conv_packed16_bytes() bytes. */
+int64_t pixie_conv_packed16_bytes(int c_out, int c_in, int ksize);
+int pixie_conv_pack_weights_f16x2(const float* d_w_oidhw, void* d_packed, int c_out, int c_in, int ksize, void* stream);
+/* F.conv3d / nn.Conv3d forward: exact-fp32 MFMA path (d_w), or the f16x3 split path (d_w16). */
 int pixie_conv3d_forward(const pixie_conv_desc* desc, void* stream);
 
 /* Per-channel sum and sum of squares over the spatial extent: d_sums[2*c] (float64). */
 int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream);
+/* Same, and additionally atomicMax's the tensor's |x|max (as float bits) into *d_amax (caller zeroes it). */
+int pixie_channel_stats(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, void* stream);
+/* |x|max of `count` floats, atomicMax'ed (as float bits) into *d_slot (caller zeroes it). */
+int pixie_tensor_amax(const float* d_x, int64_t count, uint32_t* d_slot, void* stream);
 /* Turn channel sums into the prologue's (a,b):
  *  mode 0: LayerNorm([D,H,W]) statistics per channel (biased var, eps): a = rstd, b = -mean*rstd
  *          (affine gamma/beta are spatial and applied in the conv prologue);

@@ -45,7 +45,9 @@ class ConvDesc(C.Structure):
                 ("act", C.c_int32),
                 ("d_w", C.c_void_p), ("d_bias", C.c_void_p),
                 ("c_out", C.c_int32),
-                ("d_residual", C.c_void_p), ("d_out", C.c_void_p)]
+                ("d_residual", C.c_void_p), ("d_out", C.c_void_p),
+                ("d_w16", C.c_void_p), ("d_in_amax0", C.c_void_p), ("d_in_amax1", C.c_void_p),
+                ("in_bound", C.c_float)]
 
 
 # every symbol include/pixie_hip.h declares: name -> (restype, argtypes)
@@ -74,7 +76,11 @@ SIGNATURES = {
     "pixie_mpm_kernel_times": (_I, [_VP, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
     "pixie_conv_cout_padded": (_I, [_I]),
     "pixie_conv_pack_weights": (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    "pixie_conv_packed16_bytes": (_I64, [_I, _I, _I]),
+    "pixie_conv_pack_weights_f16x2": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "pixie_conv3d_forward": (_I, [C.POINTER(ConvDesc), _VP]),
+    "pixie_channel_stats": (_I, [_VP, _I, _I64, _VP, _VP, _VP]),
+    "pixie_tensor_amax": (_I, [_VP, _I64, _VP, _VP]),
     "pixie_channel_sums": (_I, [_VP, _I, _I64, _VP, _VP]),
     "pixie_norm_finalize": (_I, [_VP, _I, _I64, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),

@@ -230,6 +230,7 @@ static int launch_variant(const ConvArgs& a, size_t lds_bytes, dim3 grid, hipStr
 
 }  // namespace pixie
 
+namespace pixie { int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st); }
 using namespace pixie;
 
 extern "C" int pixie_conv_cout_padded(int c_out) { return (c_out + 31) / 32 * 32; }
@@ -245,7 +246,7 @@ extern "C" int pixie_conv_pack_weights(const float* d_w, float* d_packed, int c_
 }
 
 extern "C" int pixie_conv3d_forward(const pixie_conv_desc* d, void* stream) {
-    PX_REQUIRE(d && d->d_in0 && d->d_w && d->d_out, "pixie_conv3d_forward: null pointer in descriptor");
+    PX_REQUIRE(d && d->d_in0 && (d->d_w || d->d_w16) && d->d_out, "pixie_conv3d_forward: null pointer in descriptor");
     PX_REQUIRE(d->ksize == 1 || d->ksize == 3, "pixie_conv3d_forward: ksize must be 1 or 3 (got %d)", d->ksize);
     PX_REQUIRE(d->stride == 1 || d->stride == 2, "pixie_conv3d_forward: stride must be 1 or 2 (got %d)", d->stride);
     PX_REQUIRE(d->upsample == 0 || d->upsample == 1, "pixie_conv3d_forward: upsample must be 0 or 1");
@@ -254,6 +255,8 @@ extern "C" int pixie_conv3d_forward(const pixie_conv_desc* d, void* stream) {
     PX_REQUIRE((d->d_pro_a == nullptr) == (d->d_pro_b == nullptr), "pixie_conv3d_forward: pro_a/pro_b must come together");
     PX_REQUIRE((d->d_gamma == nullptr) == (d->d_beta == nullptr), "pixie_conv3d_forward: gamma/beta must come together");
     PX_REQUIRE(!(d->d_gamma && d->upsample), "pixie_conv3d_forward: spatial affine with upsample is not in the reference graph");
+
+    if (d->d_w16) return conv3d_f16x3_forward(d, as_stream(stream));
 
     ConvArgs a{};
     a.in0 = d->d_in0; a.in1 = d->d_in1; a.c0 = d->c0; a.cin = d->c0 + d->c1;

@@ -17,12 +17,14 @@ namespace pixie {
 // grid = (splits, channels); each block reduces one contiguous segment of one channel with float4
 // loads (HBM-bound: one read of the tensor), fp32 per-thread partials over <= a few hundred
 // elements, fp64 from the block reduction on, one fp64 atomic pair per block.
-__global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ x, long spatial, long seg, double* __restrict__ sums) {
+__global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ x, long spatial, long seg, double* __restrict__ sums,
+                                                           unsigned* __restrict__ amax) {
     const int c = blockIdx.y;
     const long begin = (long)blockIdx.x * seg;
     const long end = begin + seg < spatial ? begin + seg : spatial;
     const float* p = x + (size_t)c * spatial;
     double s1 = 0.0, s2 = 0.0;
+    float mx = 0.0f;
     const bool vec_ok = ((reinterpret_cast<size_t>(p + begin) & 15) == 0);
     long i = begin + (long)threadIdx.x * 4;
     if (vec_ok) {
@@ -32,18 +34,21 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
             const float4 v = *reinterpret_cast<const float4*>(p + i);
             a1 += (v.x + v.y) + (v.z + v.w);
             a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
             if (++cnt == 64) { s1 += a1; s2 += a2; a1 = 0.f; a2 = 0.f; cnt = 0; }
         }
         s1 += a1; s2 += a2;
-        for (long k = i; k < end && k < i + 4; ++k) { const float v = p[k]; s1 += v; s2 += (double)v * v; }
+        for (long k = i; k < end && k < i + 4; ++k) { const float v = p[k]; s1 += v; s2 += (double)v * v; mx = fmaxf(mx, fabsf(v)); }
     } else {
-        for (long k = begin + threadIdx.x; k < end; k += 256) { const float v = p[k]; s1 += v; s2 += (double)v * v; }
+        for (long k = begin + threadIdx.x; k < end; k += 256) { const float v = p[k]; s1 += v; s2 += (double)v * v; mx = fmaxf(mx, fabsf(v)); }
     }
     // wave reduce (64 lanes) then across the 4 waves through LDS
     for (int off = 32; off > 0; off >>= 1) {
         s1 += __shfl_down(s1, off, 64);
         s2 += __shfl_down(s2, off, 64);
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
     }
+    if (amax && (threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
     __shared__ double red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
@@ -222,8 +227,8 @@ static int launch_attention(const float* qkv, float* out, int T, hipStream_t st)
 
 using namespace pixie;
 
-extern "C" int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream) {
-    PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_sums: bad arguments");
+extern "C" int pixie_channel_stats(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, void* stream) {
+    PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_stats: bad arguments");
     hipStream_t st = as_stream(stream);
     PX_CHECK_HIP(hipMemsetAsync(d_sums, 0, (size_t)channels * 2 * sizeof(double), st));
     // segments of >= 16 Ki elements, at most ~2048 blocks in total
@@ -233,9 +238,14 @@ extern "C" int pixie_channel_sums(const float* d_x, int channels, int64_t spatia
     long seg = (spatial + splits - 1) / splits;
     seg = (seg + 3) & ~3L;  // keep float4 alignment of segment starts
     splits = (spatial + seg - 1) / seg;
-    hipLaunchKernelGGL(channel_sums_kernel, dim3((unsigned)splits, (unsigned)channels), dim3(256), 0, st, d_x, (long)spatial, seg, d_sums);
+    hipLaunchKernelGGL(channel_sums_kernel, dim3((unsigned)splits, (unsigned)channels), dim3(256), 0, st, d_x, (long)spatial, seg, d_sums,
+                       reinterpret_cast<unsigned*>(d_amax));
     PX_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream) {
+    return pixie_channel_stats(d_x, channels, spatial, d_sums, nullptr, stream);
 }
 
 extern "C" int pixie_norm_finalize(const double* d_sums, int channels, int64_t spatial, int mode, int groups, double eps,

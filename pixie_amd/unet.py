@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -26,6 +27,10 @@ from ._lib import ConvDesc, check
 from .unet_plan import Block, UNetConfig, UNetPlan, build_plan, param_shapes, is_norm_key
 
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
+# "f16x3": stride-1 convolutions with 16-aligned channel counts run on the f16 matrix cores with every fp32 operand
+# split into fp16 hi+lo (three MFMAs per product, fp32 accumulate; csrc/conv3d_f16x3.hip).  "f32": every convolution
+# on the exact-fp32 MFMA kernel (csrc/conv3d_mfma.hip).  Both are HIP paths; there is no CPU path.
+DEFAULT_PRECISION = os.environ.get("PIXIE_CONV_PRECISION", "f16x3")
 _ZERO_INIT_SUFFIXES = (".out_layers.3.weight", ".out_layers.3.bias", ".proj_out.weight", ".proj_out.bias",
                        "unet.out.2.weight", "unet.out.2.bias")
 
@@ -60,10 +65,27 @@ class HipOps:
         check(self.lib.pixie_conv_pack_weights(_ptr(w), _ptr(packed), cout, cin, k, self.stream), "pixie_conv_pack_weights")
         return packed
 
-    def conv(self, parts: Sequence[torch.Tensor], packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ksize: int,
+    def pack_conv16(self, weight: torch.Tensor) -> torch.Tensor:
+        """fp16 hi/lo split + MFMA A-operand swizzle of a conv weight (device side, no host sync)."""
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        nbytes = self.lib.pixie_conv_packed16_bytes(cout, cin, k)
+        if nbytes <= 0:
+            raise _lib.PixieHipError(f"f16x3 packing needs c_in % 8 == 0 (got {cin})")
+        w = weight.detach().to(self.device, torch.float32).contiguous()
+        packed = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        check(self.lib.pixie_conv_pack_weights_f16x2(_ptr(w), _ptr(packed), cout, cin, k, self.stream), "pixie_conv_pack_weights_f16x2")
+        return packed
+
+    @staticmethod
+    def f16x3_ok(parts: Sequence[torch.Tensor], stride: int) -> bool:
+        cin = sum(int(p.shape[0]) for p in parts)
+        return stride == 1 and cin % 16 == 0 and int(parts[0].shape[0]) % 8 == 0
+
+    def conv(self, parts: Sequence[torch.Tensor], packed_w: Optional[torch.Tensor], bias: Optional[torch.Tensor], cout: int, ksize: int,
              stride: int = 1, upsample: bool = False, pro: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
-             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+             residual: Optional[torch.Tensor] = None, w16: Optional[torch.Tensor] = None,
+             in_amax: Optional[Sequence[torch.Tensor]] = None, in_bound: float = 0.0) -> torch.Tensor:
         x0 = parts[0]
         x1 = parts[1] if len(parts) > 1 else None
         cin0, d, h, w = x0.shape
@@ -86,7 +108,11 @@ class HipOps:
         desc.d_gamma = affine[0].data_ptr() if affine is not None else None
         desc.d_beta = affine[1].data_ptr() if affine is not None else None
         desc.act = act
-        desc.d_w = packed_w.data_ptr()
+        desc.d_w = packed_w.data_ptr() if packed_w is not None else None
+        desc.d_w16 = w16.data_ptr() if w16 is not None else None
+        desc.d_in_amax0 = in_amax[0].data_ptr() if in_amax else None
+        desc.d_in_amax1 = in_amax[1].data_ptr() if in_amax and len(in_amax) > 1 else None
+        desc.in_bound = float(in_bound)
         desc.d_bias = bias.data_ptr() if bias is not None else None
         desc.c_out = cout
         desc.d_residual = residual.data_ptr() if residual is not None else None
@@ -99,6 +125,14 @@ class HipOps:
         spatial = x.numel() // c
         sums = torch.empty((c, 2), device=self.device, dtype=torch.float64)
         check(self.lib.pixie_channel_sums(_ptr(x), c, spatial, _ptr(sums), self.stream), "pixie_channel_sums")
+        return sums
+
+    def channel_stats(self, x: torch.Tensor, amax_slot: torch.Tensor) -> torch.Tensor:
+        """channel_sums + the tensor's |x|max (float bits) atomicMax'ed into amax_slot (a zeroed int32[1] view)."""
+        c = x.shape[0]
+        spatial = x.numel() // c
+        sums = torch.empty((c, 2), device=self.device, dtype=torch.float64)
+        check(self.lib.pixie_channel_stats(_ptr(x), c, spatial, _ptr(sums), _ptr(amax_slot), self.stream), "pixie_channel_stats")
         return sums
 
     def norm_finalize(self, sums: torch.Tensor, spatial: int, mode: int, groups: int = 1, eps: float = 1e-5,
@@ -129,12 +163,21 @@ class UNetRunner:
     """Walks the plan for one sample.  `ops` is HipOps in the product; tests inject a torch reference
     implementation of the same five operators to check the wiring on a CPU."""
 
-    def __init__(self, cfg: UNetConfig, params: Dict[str, torch.Tensor], ops):
+    def __init__(self, cfg: UNetConfig, params: Dict[str, torch.Tensor], ops, precision: Optional[str] = None):
         self.cfg = cfg
         self.plan: UNetPlan = build_plan(cfg)
         self.p = params
         self.ops = ops
+        self.precision = precision or DEFAULT_PRECISION
+        if self.precision not in ("f16x3", "f32"):
+            raise ValueError(f"unknown conv precision {self.precision!r}")
         self._packed: Dict[str, Tuple[int, int, torch.Tensor]] = {}
+        self._packed16: Dict[str, Tuple[int, int, torch.Tensor]] = {}
+        self._bounds: Dict[str, Tuple[int, int, float, float]] = {}
+
+    @property
+    def _f16x3(self) -> bool:
+        return self.precision == "f16x3" and hasattr(self.ops, "pack_conv16")
 
     # -- parameter helpers
     def _w(self, key: str) -> torch.Tensor:
@@ -144,14 +187,69 @@ class UNetRunner:
             self._packed[key] = (t.data_ptr(), t._version, self.ops.pack_conv(t))
         return self._packed[key][2]
 
+    def _w16(self, key: str) -> torch.Tensor:
+        t = self.p[key + ".weight"]
+        ent = self._packed16.get(key)
+        if ent is None or ent[0] != t.data_ptr() or ent[1] != t._version:
+            self._packed16[key] = (t.data_ptr(), t._version, self.ops.pack_conv16(t))
+        return self._packed16[key][2]
+
     def _b(self, key: str) -> torch.Tensor:
         return self.p[key + ".bias"]
 
-    def _sums(self, cache: dict, t: torch.Tensor) -> torch.Tensor:
+    def _absmax(self, key: str) -> Tuple[float, float]:
+        """(max|weight|, max|bias|) of a normalisation layer, cached per parameter version (one host sync each)."""
+        w, bb = self.p[key + ".weight"], self.p[key + ".bias"]
+        ent = self._bounds.get(key)
+        if ent is None or ent[0] != w._version or ent[1] != bb._version:
+            self._bounds[key] = (w._version, bb._version, float(w.abs().max()), float(bb.abs().max()))
+            ent = self._bounds[key]
+        return ent[2], ent[3]
+
+    def _norm_bound(self, key: str, count: int) -> float:
+        """Bound on |normalised * weight + bias| when `count` elements share the statistics: a standardised sample
+        of n values cannot exceed sqrt(n-1) in magnitude.  LeakyReLU/SiLU do not increase magnitudes."""
+        wmax, bmax = self._absmax(key)
+        return math.sqrt(float(count)) * wmax + bmax + 1e-30
+
+    def _stats(self, cache: dict, t: torch.Tensor):
         k = id(t)
         if k not in cache:
-            cache[k] = (t, self.ops.channel_sums(t))  # keep t alive so id() stays unique
-        return cache[k][1]
+            if hasattr(self.ops, "channel_stats"):
+                pool = cache.get("_slots")
+                if pool is None:
+                    pool = cache["_slots"] = torch.zeros(1024, dtype=torch.int32, device=t.device)
+                    cache["_next"] = 0
+                i = cache["_next"]
+                cache["_next"] = i + 1
+                slot = pool[i:i + 1]
+                cache[k] = (t, self.ops.channel_stats(t, slot), slot)  # keep t alive so id() stays unique
+            else:
+                cache[k] = (t, self.ops.channel_sums(t), None)
+        return cache[k]
+
+    def _sums(self, cache: dict, t: torch.Tensor) -> torch.Tensor:
+        return self._stats(cache, t)[1]
+
+    def _amax(self, cache: dict, t: torch.Tensor) -> torch.Tensor:
+        return self._stats(cache, t)[2]
+
+    def _conv(self, cache: dict, parts: List[torch.Tensor], wkey: str, cout: int, ksize: int, *, stride: int = 1,
+              upsample: bool = False, pro=None, affine_key: Optional[str] = None, act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None, bound: float = 0.0) -> torch.Tensor:
+        """One convolution launch.  `bound` bounds the magnitude of the prologue's output (needed by the f16x3
+        kernel to place the tensor in the fp16 range); raw inputs use their device-side |x|max instead."""
+        ops = self.ops
+        affine = (self.p[affine_key + ".weight"], self.p[affine_key + ".bias"]) if affine_key else None
+        if not (self._f16x3 and ops.f16x3_ok(parts, stride)):
+            return ops.conv(parts, self._w(wkey), self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro,
+                            affine=affine, act=act, residual=residual)
+        if pro is None and affine is None:
+            kw = dict(in_amax=[self._amax(cache, t) for t in parts])
+        else:
+            kw = dict(in_bound=bound)
+        return ops.conv(parts, None, self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro, affine=affine,
+                        act=act, residual=residual, w16=self._w16(wkey), **kw)
 
     # -- blocks
     def _res(self, b: Block, parts: List[torch.Tensor], cache: dict) -> torch.Tensor:
@@ -160,16 +258,15 @@ class UNetRunner:
         spatial = parts[0][0].numel()
         sums = torch.cat([self._sums(cache, t) for t in parts], dim=0) if len(parts) > 1 else self._sums(cache, parts[0])
         pro = ops.norm_finalize(sums, spatial, 0)
-        h = ops.conv(parts, self._w(p + ".in_layers.2"), self._b(p + ".in_layers.2"), b.cout, 3, pro=pro,
-                     affine=(self.p[p + ".in_layers.0.weight"], self.p[p + ".in_layers.0.bias"]), act=ACT_LEAKY)
+        h = self._conv(cache, parts, p + ".in_layers.2", b.cout, 3, pro=pro, affine_key=p + ".in_layers.0", act=ACT_LEAKY,
+                       bound=self._norm_bound(p + ".in_layers.0", spatial))
         pro2 = ops.norm_finalize(self._sums(cache, h), spatial, 0)
         if b.cin != b.cout:
-            skip = ops.conv(parts, self._w(p + ".skip_connection"), self._b(p + ".skip_connection"), b.cout, 1)
+            skip = self._conv(cache, parts, p + ".skip_connection", b.cout, 1)
         else:
             skip = parts[0]
-        return ops.conv([h], self._w(p + ".out_layers.3"), self._b(p + ".out_layers.3"), b.cout, 3, pro=pro2,
-                        affine=(self.p[p + ".out_layers.0.weight"], self.p[p + ".out_layers.0.bias"]), act=ACT_LEAKY,
-                        residual=skip)
+        return self._conv(cache, [h], p + ".out_layers.3", b.cout, 3, pro=pro2, affine_key=p + ".out_layers.0", act=ACT_LEAKY,
+                          residual=skip, bound=self._norm_bound(p + ".out_layers.0", spatial))
 
     def _attn(self, b: Block, x: torch.Tensor, cache: dict) -> torch.Tensor:
         """AttentionBlock._forward, diffusion_network.py:213-221"""
@@ -178,12 +275,11 @@ class UNetRunner:
         spatial = x[0].numel()
         pro = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[p + ".norm.weight"],
                                 bias=self.p[p + ".norm.bias"])
-        qkv = ops.conv([x], self._w(p + ".qkv"), self._b(p + ".qkv"), 3 * c, 1, pro=pro)
+        qkv = self._conv(cache, [x], p + ".qkv", 3 * c, 1, pro=pro, bound=self._norm_bound(p + ".norm", spatial * (c // 32)))
         att = ops.attention(qkv.reshape(3 * c, spatial), c, spatial).reshape(x.shape)
-        return ops.conv([att], self._w(p + ".proj_out"), self._b(p + ".proj_out"), c, 1, residual=x)
+        return self._conv(cache, [att], p + ".proj_out", c, 1, residual=x)
 
     def _block(self, b: Block, parts: List[torch.Tensor], cache: dict) -> torch.Tensor:
-        ops = self.ops
         if b.kind == "res":
             return self._res(b, parts, cache)
         assert len(parts) == 1
@@ -191,9 +287,9 @@ class UNetRunner:
         if b.kind == "attn":
             return self._attn(b, x, cache)
         if b.kind == "down":
-            return ops.conv([x], self._w(b.prefix + ".op"), self._b(b.prefix + ".op"), b.cout, 3, stride=2)
+            return self._conv(cache, [x], b.prefix + ".op", b.cout, 3, stride=2)
         if b.kind == "up":
-            return ops.conv([x], self._w(b.prefix + ".conv"), self._b(b.prefix + ".conv"), b.cout, 3, upsample=True)
+            return self._conv(cache, [x], b.prefix + ".conv", b.cout, 3, upsample=True)
         raise ValueError(b.kind)
 
     def forward(self, feat: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
@@ -202,26 +298,29 @@ class UNetRunner:
         cache: dict = {}
         spatial = feat[0].numel()
         x = feat
-        pro_in, act_in = None, ACT_NONE
+        pro_in, act_in, bound_in = None, ACT_NONE, 0.0
         if cfg.has_projector:  # FeatureProjector.net, diffusion_network.py:556-585
             q = "projector.net."
             if cfg.projector_hidden is None:
-                x = ops.conv([x], self._w(q + "0"), self._b(q + "0"), cfg.cond_dim, 1)
-                pro_in = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=max(cfg.cond_dim // 2, 1),
+                g = max(cfg.cond_dim // 2, 1)
+                x = self._conv(cache, [x], q + "0", cfg.cond_dim, 1)
+                pro_in = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=g,
                                            weight=self.p[q + "1.weight"], bias=self.p[q + "1.bias"])
                 act_in = ACT_SILU
+                bound_in = self._norm_bound(q + "1", spatial * (cfg.cond_dim // g))
             else:
                 hid = cfg.projector_hidden
-                x = ops.conv([x], self._w(q + "0"), self._b(q + "0"), hid, 1)
+                x = self._conv(cache, [x], q + "0", hid, 1)
                 pro = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[q + "1.weight"], bias=self.p[q + "1.bias"])
-                x = ops.conv([x], self._w(q + "3"), self._b(q + "3"), hid, 3, pro=pro, act=ACT_SILU)
+                x = self._conv(cache, [x], q + "3", hid, 3, pro=pro, act=ACT_SILU, bound=self._norm_bound(q + "1", spatial * (hid // 32)))
                 pro = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[q + "4.weight"], bias=self.p[q + "4.bias"])
-                x = ops.conv([x], self._w(q + "6"), self._b(q + "6"), cfg.cond_dim, 1, pro=pro, act=ACT_SILU)
+                x = self._conv(cache, [x], q + "6", cfg.cond_dim, 1, pro=pro, act=ACT_SILU, bound=self._norm_bound(q + "4", spatial * (hid // 32)))
                 pro_in = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[q + "7.weight"], bias=self.p[q + "7.bias"])
+                bound_in = self._norm_bound(q + "7", spatial * max(cfg.cond_dim // 32, 1))
         plan = self.plan
         hs: List[torch.Tensor] = []
         first = plan.input_blocks[0][0]
-        h = ops.conv([x], self._w(first.prefix), self._b(first.prefix), first.cout, 3, pro=pro_in, act=act_in)
+        h = self._conv(cache, [x], first.prefix, first.cout, 3, pro=pro_in, act=act_in, bound=bound_in)
         hs.append(h)
         if taps is not None:
             taps["unet.input_blocks.0"] = h
@@ -246,8 +345,8 @@ class UNetRunner:
             if taps is not None:
                 taps[seq[0].prefix.rsplit(".", 1)[0]] = h
         pro = ops.norm_finalize(self._sums(cache, h), h[0].numel(), 0)
-        return ops.conv([h], self._w("unet.out.2"), self._b("unet.out.2"), cfg.out_channels, 3, pro=pro,
-                        affine=(self.p["unet.out.0.weight"], self.p["unet.out.0.bias"]), act=ACT_LEAKY)
+        return self._conv(cache, [h], "unet.out.2", cfg.out_channels, 3, pro=pro, affine_key="unet.out.0", act=ACT_LEAKY,
+                          bound=self._norm_bound("unet.out.0", h[0].numel()))
 
 
 class _Node(nn.Module):
@@ -269,6 +368,7 @@ class _PixieUNet(nn.Module):
                 node = node._modules[name]
             node.register_parameter(parts[-1], nn.Parameter(self._init(key, shape, shapes, gen), requires_grad=False))
         self._runner: Optional[UNetRunner] = None
+        self.conv_precision = DEFAULT_PRECISION  # "f16x3" (default) or "f32" (exact-fp32 MFMA everywhere)
 
     @staticmethod
     def _init(key, shape, shapes, gen) -> torch.Tensor:
@@ -297,8 +397,8 @@ class _PixieUNet(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda" or feat_grid.device != dev:
             raise _lib.PixieHipError("model and input must live on the same HIP device (no CPU fallback)")
-        if self._runner is None or self._runner.ops.device != dev:
-            self._runner = UNetRunner(self.cfg, self._params(), HipOps(dev))
+        if self._runner is None or self._runner.ops.device != dev or self._runner.precision != self.conv_precision:
+            self._runner = UNetRunner(self.cfg, self._params(), HipOps(dev), precision=self.conv_precision)
         else:
             self._runner.p = self._params()
         x = feat_grid.detach().to(torch.float32).contiguous()

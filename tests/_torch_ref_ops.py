@@ -72,3 +72,82 @@ class TorchRefOps:
         for i in range(logits.shape[0]):
             out[3 + i] = (am == i).float()
         return out, am.int()
+
+
+def _scale_exponent(bound: float) -> int:
+    """Mirror of scale_exponent() in pixie_amd/csrc/conv3d_f16x3.hip."""
+    import math
+    if not (bound > 0.0) or math.isinf(bound) or math.isnan(bound):
+        return 0
+    eb = math.frexp(bound)[1] - 1  # bound in [2^eb, 2^(eb+1))
+    return max(-100, min(100, 14 - eb))
+
+
+def _split16(x: torch.Tensor, e: int):
+    xs = x.float() * (2.0 ** e)
+    hi = xs.half()
+    assert torch.isfinite(hi).all(), "fp16 overflow: the scale bound was violated"
+    lo = (xs - hi.float()).half()
+    return hi.float(), lo.float()
+
+
+class TorchRefOpsF16x3(TorchRefOps):
+    """CPU emulation of the f16x3 convolution arithmetic (fp16 hi/lo split of both operands, three products,
+    fp32 accumulation) with the same scale selection as the HIP kernel, so that the CPU suite can (a) check that
+    UNetRunner hands every f16x3 launch a valid magnitude bound and (b) measure the end-to-end error of the
+    scheme against the fp32 oracle.  TEST INFRASTRUCTURE ONLY."""
+
+    n_f16x3 = 0
+    n_exact = 0
+
+    def pack_conv16(self, weight):
+        return weight.detach().to(torch.float32)
+
+    @staticmethod
+    def f16x3_ok(parts, stride):
+        cin = sum(int(p.shape[0]) for p in parts)
+        return stride == 1 and cin % 16 == 0 and int(parts[0].shape[0]) % 8 == 0
+
+    def channel_stats(self, x, amax_slot):
+        amax_slot.copy_(x.abs().max().reshape(1).float().view(torch.int32))
+        return self.channel_sums(x)
+
+    def conv(self, parts, packed_w, bias, cout, ksize, stride=1, upsample=False, pro=None, affine=None, act=0, residual=None,
+             w16=None, in_amax=None, in_bound=0.0):
+        if w16 is None:
+            TorchRefOpsF16x3.n_exact += 1
+            return super().conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, residual)
+        TorchRefOpsF16x3.n_f16x3 += 1
+        x = torch.cat(list(parts), dim=0) if len(parts) > 1 else parts[0]
+        if pro is not None:
+            x = x * pro[0][:, None, None, None] + pro[1][:, None, None, None]
+        if affine is not None:
+            x = x * affine[0][None] + affine[1][None]
+        if act == 1:
+            x = F.leaky_relu(x, 0.02)
+        elif act == 2:
+            x = F.silu(x)
+        if in_amax:
+            assert pro is None and affine is None and len(in_amax) == len(parts)
+            bound = max(float(s.view(torch.float32)[0]) for s in in_amax)
+        else:
+            bound = float(in_bound)
+            assert bound > 0.0
+        assert float(x.abs().max()) <= bound * (1 + 1e-6), (float(x.abs().max()), bound)
+        ex = _scale_exponent(bound)
+        w = w16 if w16.dim() == 5 else w16[:, :, :, None, None]
+        ew = _scale_exponent(float(w.abs().max()))
+        xh, xl = _split16(x, ex)
+        wh, wl = _split16(w, ew)
+        if upsample:
+            xh = F.interpolate(xh[None], scale_factor=2, mode="nearest")[0]
+            xl = F.interpolate(xl[None], scale_factor=2, mode="nearest")[0]
+        pad = 1 if ksize == 3 else 0
+        y = F.conv3d(xl[None], wh, None, padding=pad) + F.conv3d(xh[None], wl, None, padding=pad) + F.conv3d(xh[None], wh, None, padding=pad)
+        y = y[0] * (2.0 ** (-ex - ew))
+        if bias is not None:
+            y = y + bias[:, None, None, None]
+        if residual is not None:
+            y = y + residual
+        assert y.shape[0] == cout
+        return y

@@ -28,11 +28,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.pixie_build_arch() == b"gfx950"
 
 
-def test_struct_layouts_match_header():
-    # sizes implied by the C declarations (natural alignment)
-    assert C.sizeof(_lib.BCDesc) == 16 + 12 * 8 + 3 * 8
-    assert C.sizeof(_lib.PModDesc) == 8 + 21 * 8 + 6 * 8
-    assert C.sizeof(_lib.ConvDesc) % 8 == 0 and _lib.ConvDesc.d_out.offset == C.sizeof(_lib.ConvDesc) - 8
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof/offsetof of every struct field, as gcc lays out include/pixie_hip.h, equal the ctypes mirrors."""
+    import subprocess
+    structs = {"pixie_bc_desc": _lib.BCDesc, "pixie_pmod_desc": _lib.PModDesc, "pixie_conv_desc": _lib.ConvDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "pixie_hip.h")}"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device failure mode")

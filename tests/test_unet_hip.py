@@ -68,8 +68,25 @@ CONV_CASES = [
 ]
 
 
+def _prologue_cpu(parts, pro, affine, act):
+    x = torch.cat(parts, 0)
+    if pro is not None:
+        x = x * pro[0][:, None, None, None] + pro[1][:, None, None, None]
+    if affine is not None:
+        x = x * affine[0][None] + affine[1][None]
+    return F.leaky_relu(x, 0.02) if act == 1 else (F.silu(x) if act == 2 else x)
+
+
+def _amax_slots(ops, tensors):
+    slots = torch.zeros(len(tensors), dtype=torch.int32, device=ops.device)
+    for i, t in enumerate(tensors):
+        ops.channel_stats(t, slots[i:i + 1])
+    return [slots[i:i + 1] for i in range(len(tensors))]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
-def test_conv3d_operator(ops, case):
+def test_conv3d_operator(ops, case, precision):
     cins, cout, dims, k, stride, ups, prologue, act, has_res = case
     g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
     parts = [torch.randn((c,) + dims, generator=g) for c in cins]
@@ -83,13 +100,47 @@ def test_conv3d_operator(ops, case):
     ref = ref_no_res + residual.double() if has_res else ref_no_res
     dev = ops.device
     to = lambda t: t.to(dev) if t is not None else None
-    out = ops.conv([to(p) for p in parts], ops.pack_conv(to(w)), to(b), cout, k, stride=stride, upsample=ups,
-                   pro=tuple(map(to, pro)) if pro else None, affine=tuple(map(to, affine)) if affine else None, act=act,
-                   residual=to(residual))
+    dparts = [to(p) for p in parts]
+    kw = dict(stride=stride, upsample=ups, pro=tuple(map(to, pro)) if pro else None,
+              affine=tuple(map(to, affine)) if affine else None, act=act, residual=to(residual))
+    if precision == "f16x3":
+        if not ops.f16x3_ok(dparts, stride):
+            pytest.skip("layer shape stays on the exact-fp32 kernel (stride 2 or channels not 16-aligned)")
+        if prologue:  # host bound on |prologue(x)|, deliberately loose by 3x: any valid bound must work
+            kw["in_bound"] = 3.0 * float(_prologue_cpu(parts, pro, affine, act).abs().max())
+        else:
+            kw["in_amax"] = _amax_slots(ops, dparts)
+        out = ops.conv(dparts, None, to(b), cout, k, w16=ops.pack_conv16(to(w)), **kw)
+        tol = 2e-6   # ~2^-22 per product from the dropped lo*lo term and the 22-bit operands
+    else:
+        out = ops.conv(dparts, ops.pack_conv(to(w)), to(b), cout, k, **kw)
+        tol = 1e-5
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(ref.shape)
     err = rel_l2(out.cpu().numpy(), ref.numpy())
-    assert err < 1e-5, err
+    print(f"{precision} conv {case}: rel-L2 {err:.3e}")
+    assert err < tol, err
+
+
+def test_conv3d_f16x3_dynamic_range(ops):
+    """Inputs spanning 1e-6 .. 1e+5 in magnitude across channels and a weight tensor with a 1e4 spread: the
+    device-side power-of-two scaling must keep the split exact enough (no fp16 overflow, no flushed lo parts)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((32, 8, 8, 32), generator=g)
+    x *= (10.0 ** torch.linspace(-6, 5, 32))[:, None, None, None]
+    w = torch.randn((64, 32, 3, 3, 3), generator=g) / 30
+    w[:8] *= 1e2; w[8:16] *= 1e-2
+    ref = ref_conv([x], w, torch.zeros(64))
+    dx = x.to(ops.device)
+    out = ops.conv([dx], None, None, 64, 3, w16=ops.pack_conv16(w.to(ops.device)), in_amax=_amax_slots(ops, [dx]))
+    assert torch.isfinite(out).all()
+    err = rel_l2(out.cpu().numpy(), ref.numpy())
+    print(f"f16x3 dynamic-range conv: rel-L2 {err:.3e}")
+    assert err < 2e-6, err
+    # per-output-channel error relative to that channel's own norm: small-weight channels must not drown
+    o, r = out.cpu().double().reshape(64, -1), ref.reshape(64, -1)
+    per = ((o - r).norm(dim=1) / r.norm(dim=1)).max().item()
+    assert per < 1e-5, per
 
 
 def test_conv3d_residual_may_alias_output_and_is_deterministic(ops):
@@ -101,7 +152,8 @@ def test_conv3d_residual_may_alias_output_and_is_deterministic(ops):
     assert torch.equal(a, b)  # no atomics, fixed accumulation order => bitwise reproducible
 
 
-def test_conv3d_full_resolution_spot_check(ops):
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_conv3d_full_resolution_spot_check(ops, precision):
     """BASELINE config 2 size: the 64->64 3^3 conv on a 128^3 grid (464 GFLOP), checked exactly on random
     output voxels against a float64 evaluation of the 3x3x3x64 stencil (size-independent property)."""
     g = torch.Generator().manual_seed(7)
@@ -109,7 +161,11 @@ def test_conv3d_full_resolution_spot_check(ops):
     x = torch.randn((64, D, D, D), generator=g)
     w = torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)
     b = torch.randn(64, generator=g)
-    out = ops.conv([x.to(ops.device)], ops.pack_conv(w.to(ops.device)), b.to(ops.device), 64, 3).cpu()
+    dx = x.to(ops.device)
+    if precision == "f16x3":
+        out = ops.conv([dx], None, b.to(ops.device), 64, 3, w16=ops.pack_conv16(w.to(ops.device)), in_amax=_amax_slots(ops, [dx])).cpu()
+    else:
+        out = ops.conv([dx], ops.pack_conv(w.to(ops.device)), b.to(ops.device), 64, 3).cpu()
     xp = F.pad(x, (1, 1, 1, 1, 1, 1)).double()
     rng = np.random.default_rng(0)
     pts = rng.integers(0, D, size=(64, 3))
@@ -168,9 +224,11 @@ def test_combine_predictions(ops):
     assert torch.equal(am.cpu().long(), torch.argmax(logits, 0))
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_network_matches_reference_golden(hip_device, name):
-    """SegmentationUNet / RegressionUNet on the HIP path vs outputs of the reference's own modules."""
+def test_network_matches_reference_golden(hip_device, name, precision):
+    """SegmentationUNet / RegressionUNet on the HIP path vs outputs of the reference's own modules, with the
+    convolutions on the f16x3 split path (product default) and on the exact-fp32 MFMA path."""
     from pixie_amd.unet import RegressionUNet, SegmentationUNet
     kw, wseed, iseed = CASES[name]
     g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
@@ -181,9 +239,11 @@ def test_network_matches_reference_golden(hip_device, name):
                     kw["attention_resolutions"], kw["grid_size"], oc)
         model.load_numpy_state(synthetic_state_dict(model.cfg, wseed + off))
         model = model.to(hip_device).eval()
+        model.conv_precision = precision
         taps = {}
         y = model(feat, taps).cpu().numpy()
         err = rel_l2(y, g[head])
+        print(f"{name}/{head}/{precision}: rel-L2 vs reference golden {err:.3e}")
         if err >= 1e-4:  # localise the first diverging layer
             sd = synthetic_state_dict(model.cfg, wseed + off)
             taps_o = {}

@@ -90,6 +90,31 @@ def test_runner_wiring_against_oracle(name):
         assert rel_l2(y, ref) < 2e-5
 
 
+def test_f16x3_scheme_bounds_and_accuracy():
+    """The f16x3 convolution scheme (fp16 hi/lo split of both operands, three products, fp32 accumulate), emulated
+    on the CPU with the HIP kernel's scale selection: every f16x3 launch gets a magnitude bound that really holds
+    (no fp16 overflow -- asserted inside the emulation), and the full 16^3 network stays within 1e-5 rel-L2 of the
+    fp32 oracle (the GPU parity bar is 1e-4)."""
+    from tests._torch_ref_ops import TorchRefOpsF16x3
+    kw, wseed, iseed = CASES["full16"]
+    feat = feature_grid(kw["grid_size"], kw["feature_channels"], seed=iseed)
+    feat[0, :, 3, 4, 5] *= 300.0  # outliers in the raw input exercise the device-side amax scaling
+    for head, oc, off in HEADS:
+        cfg = UNetConfig(out_channels=oc, **kw)
+        sd = synthetic_state_dict(cfg, wseed + off)
+        params = {k: torch.from_numpy(v) for k, v in sd.items()}
+        TorchRefOpsF16x3.n_f16x3 = TorchRefOpsF16x3.n_exact = 0
+        runner = UNetRunner(cfg, params, TorchRefOpsF16x3(), precision="f16x3")
+        y = runner.forward(torch.from_numpy(feat[0])).numpy()
+        ref = unet_oracle.unet_forward(sd, cfg, feat).numpy()[0]
+        err = rel_l2(y, ref)
+        print(f"{head}: f16x3 emulation rel-L2 vs fp32 oracle {err:.3e}; {TorchRefOpsF16x3.n_f16x3} f16x3 + "
+              f"{TorchRefOpsF16x3.n_exact} exact conv launches")
+        assert TorchRefOpsF16x3.n_exact == 3       # only the three stride-2 Downsample convs stay on the fp32 kernel
+        assert TorchRefOpsF16x3.n_f16x3 >= 80
+        assert err < 1e-5
+
+
 def test_fresh_reference_style_init_is_zero_output():
     """SURVEY.md 'things to know' #5: zero_module makes a freshly built network output exactly 0; our
     module keeps that construction-time behaviour (and therefore needs synthetic weights for parity)."""
