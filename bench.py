@@ -31,6 +31,7 @@ from pixie_amd.synthetic import apply_scene, feature_grid, mpm_ball_scene  # noq
 from pixie_amd.unet_plan import UNetConfig, conv_flops, synthetic_state_dict  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_f16 dense peak (no sparsity)
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec (6.3 TB/s achievable per the same guide)
 
 
@@ -46,6 +47,9 @@ def parse():
     ap.add_argument("--mpm-substeps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mpm", action="store_true")
+    ap.add_argument("--conv-precision", choices=["f16x3", "f32"], default=None,
+                    help="f16x3 (default): fp32 operands split into fp16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate; "
+                         "f32: exact-fp32 MFMA everywhere")
     return ap.parse_args()
 
 
@@ -106,6 +110,9 @@ def bench_unet(args, rank, world, device):
     seg.load_numpy_state(synthetic_state_dict(seg.cfg, 0))
     cont.load_numpy_state(synthetic_state_dict(cont.cfg, 1000))
     seg, cont = seg.to(device).eval(), cont.to(device).eval()
+    if args.conv_precision:
+        seg.conv_precision = cont.conv_precision = args.conv_precision
+    precision = seg.conv_precision
     feat = torch.from_numpy(feature_grid(D, C, seed=100 + rank)).to(device)  # scene i uses seed 100+i
 
     def step():
@@ -135,11 +142,20 @@ def bench_unet(args, rank, world, device):
         ms = agg[dom_key][0] / agg[dom_key][1]
         fl = 2.0 * 27 * 64 * 64 * D ** 3
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,2,4,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
+        if precision == "f16x3":
+            # achieved = ALGORITHMIC (fp32-equivalent) FLOP/s; the kernel issues 3 f16 MFMAs per algorithmic product,
+            # so the matrix pipe is doing 3x that.  peak = dense f16 MFMA peak; frac = achieved/peak (conservative).
+            roof = {"bound": "mfma", "kernel": "conv3d_f16x3_kernel<3,2,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
+                    "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl,
+                    "mfma_issue_ratio": 3, "mfma_hw_tflops": round(3 * ach, 1), "mfma_hw_frac": round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
+                    "vs_exact_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3)}
+        else:
+            roof = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,2,4,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
     conv_ms = sum(v[0] for v in agg.values()) / max(args.steps, 1)
-    return dict(seconds=dt, voxels=world * args.steps * D ** 3, flops_scene=flops_scene, roofline=roof,
+    return dict(seconds=dt, voxels=world * args.steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision,
                 conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(args.steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]})
 
 
@@ -230,7 +246,8 @@ def main():
             "metric": "voxels/s (128^3 U-Net fwd) + MPM particle-steps/s",
             "value": vps, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * u["seconds"] / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if u["precision"] == "f32" else "f32 (operands split fp16 hi+lo, 3 f16 MFMAs/product, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"{args.grid}^3x{args.feature_channels} feature grid -> SegmentationUNet+RegressionUNet forward "
                                    f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
                        "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
