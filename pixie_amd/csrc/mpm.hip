@@ -60,6 +60,8 @@ struct MpmPtrs {
     int *material, *selection, *perm;
     float4 *gin, *gout;
     const int4* items;           // work list: (block id, first slot, count, 0)
+    float4* part;                // [n_items][kTN]: (m*v.xyz, m) of each work item's tile, written by its P2G
+    const int2* blk_items;       // per block: (first work item, number of work items)
     unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles
 };
 
@@ -279,16 +281,33 @@ __device__ __noinline__ void p2g_scatter_global(float4* gin, int ng, Stencil st,
 // ------------------------------------------------------------------ fused block kernel
 // G2P part: g2p (mpm_utils.py:412-463).  P2G part: pre-P2G modifiers, compute_stress_from_F_trial
 // (:467-526) and p2g_apic_with_stress (:338-394).  `sp.time` is the time of the substep whose P2G runs.
-template <bool DO_G2P, bool DO_P2G, int DBG>
-__device__ __forceinline__ void particle_body(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
-                                              int oz, float (*tv)[kTN], float (*ta)[kTN]) {
+//
+// The scatter accumulates in LDS with 64-bit INTEGER atomics: ds_add_f32 retires ~1 lane per 3 cycles on gfx950
+// (193 cycles per wave-instruction, measured: scripts/microbench/lds_atomics.hip), ds_add_u64 is 11x faster.  Each
+// workgroup therefore (1) computes every particle's scatter inputs, (2) takes the workgroup maximum of a bound on
+// their contributions, (3) scales by the power of two that puts that bound at 2^50 and adds round-to-nearest
+// integers (|sum of 256| < 2^58).  The LSB is 2^-50 of the largest contribution in the tile, i.e. the tile sums are
+// exact to ~1e-15 -- tighter than any fp32 summation order -- and since integer adds commute they are bit-reproducible.
+// (A 32-bit variant -- LSB 2^-21 -- was measured first: low-mass free-surface nodes lost up to 10 % of their velocity.)
+struct ScatterIn {
+    float x[3];     // position after the G2P update (where the P2G stencil is taken)
+    float mv[3];    // mass * v
+    Mat3 A;         // mass * C' * dx
+    Mat3 T;         // -dt * vol * inv_dx * tau
+    float mass;
+    bool active;    // contributes to P2G
+};
+
+template <bool DO_G2P, bool DO_P2G>
+__device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
+                                                int oz, float (*tv)[kTN], ScatterIn& out) {
+    out.active = false;
     if (S.selection[p] != 0) return;
     const int n = S.n;
     float x[3], v[3];
     Mat3 C, Ft;
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = S.x[d * n + p];
-    bool slow = false;
 
     if (DO_G2P) {
         const Stencil st = make_stencil(x[0], x[1], x[2], S.inv_dx);
@@ -309,7 +328,7 @@ __device__ __forceinline__ void particle_body(const MpmPtrs& S, const StepParams
                 g[0] = tv[0][idx]; g[1] = tv[1][idx]; g[2] = tv[2][idx];
             }, nv, B, G);
         } else {
-            slow = true;
+            atomicAdd(S.oob + 1, 1ull);
             float acc[21];
             g2p_gather_global(S.gout, S.ng, st, acc);
 #pragma unroll
@@ -339,7 +358,6 @@ __device__ __forceinline__ void particle_body(const MpmPtrs& S, const StepParams
                 S.C[i * n + p] = C.m[i];
                 S.Ft[i * n + p] = Ft.m[i];
             }
-            if (slow) atomicAdd(S.oob + 1, 1ull);
             return;
         }
     } else {
@@ -367,61 +385,56 @@ __device__ __forceinline__ void particle_body(const MpmPtrs& S, const StepParams
         const float bulk = (material == 6) ? S.bulk[p] : 0.0f;
         const float mu0 = mu, lam0 = lam, ys0 = ys;
         Mat3 F, tau;
-        if (DBG == 3) { F = Ft; for (int i = 0; i < 9; ++i) tau.m[i] = 0.0f; }
-        else return_map_and_stress(material, Ft, mu, lam, bulk, ys, sp.ms, sp.dt, F, tau);
+        return_map_and_stress(material, Ft, mu, lam, bulk, ys, sp.ms, sp.dt, F, tau);
 #pragma unroll
         for (int i = 0; i < 9; ++i) S.F[i * n + p] = F.m[i];
         if (ys != ys0) S.ys[p] = ys;
         if (mu != mu0) S.mu[p] = mu;
         if (lam != lam0) S.lam[p] = lam;
 
-        const Stencil st = make_stencil(x[0], x[1], x[2], S.inv_dx);
-        if (!stencil_inside(st, S.ng)) {
-            atomicAdd(S.oob, 1ull);
-            return;
-        }
         // C' = (1-r) C + r/2 (C - C^T);  r < -0.001 => PIC (mpm_utils.py:372-379)
-        Mat3 A;  // mass * C' * dx   (dpos = (ijk - fx) * dx)
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 float c = (1.0f - sp.rpic) * C.m[3 * a + b] + sp.rpic * 0.5f * (C.m[3 * a + b] - C.m[3 * b + a]);
                 if (sp.rpic < -0.001f) c = 0.0f;
-                A.m[3 * a + b] = mass * c * S.dx;
+                out.A.m[3 * a + b] = mass * c * S.dx;  // dpos = (ijk - fx) * dx
             }
-        const float mv[3] = {mass * v[0], mass * v[1], mass * v[2]};
         const float ks = -sp.dt * S.vol[p] * S.inv_dx;  // dt * (-vol * tau * dweight), dweight = dw*w*w*inv_dx
-        Mat3 T;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) T.m[i] = ks * tau.m[i];
-        const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
-        if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
-            const int b0 = (lx * kTS + ly) * kTS + lz;
-            if (DBG != 2) p2g_scatter(st, mv, A, T, mass, [&](int i, int j, int k, const float mom[3], float m) {
-                const int idx = b0 + (i * kTS + j) * kTS + k;
-                atomicAdd(&ta[0][idx], mom[0]);
-                atomicAdd(&ta[1][idx], mom[1]);
-                atomicAdd(&ta[2][idx], mom[2]);
-                atomicAdd(&ta[3][idx], m);
-            });
-        } else {
-            slow = true;
-            float mvAT[21];
+        for (int i = 0; i < 9; ++i) out.T.m[i] = ks * tau.m[i];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) mvAT[a] = mv[a];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) { mvAT[3 + q] = A.m[q]; mvAT[12 + q] = T.m[q]; }
-            p2g_scatter_global(S.gin, S.ng, st, mvAT, mass);
-        }
-        if (slow) atomicAdd(S.oob + 1, 1ull);
+        for (int d = 0; d < 3; ++d) { out.mv[d] = mass * v[d]; out.x[d] = x[d]; }
+        out.mass = mass;
+        out.active = true;
     }
 }
 
-template <bool DO_G2P, bool DO_P2G, int DBG = 0>
-__global__ __launch_bounds__(kWG) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
+constexpr double kMagicD = 6755399441055744.0;            // 1.5 * 2^52: x + kMagicD has ulp 1 for |x| < 2^51
+constexpr long long kMagicBitsD = 0x4338000000000000ll;
+
+// power of two s with bound * s in [2^49, 2^50)  (1 when the bound is zero / not finite)
+__device__ __forceinline__ float scale_for(float bound) {
+    const unsigned bits = __float_as_uint(bound);
+    const int eb = (int)((bits >> 23) & 0xffu) - 127;
+    if (!(bound > 0.0f) || eb > 120) return 1.0f;
+    int e = 49 - eb;
+    e = e > 120 ? 120 : (e < -80 ? -80 : e);
+    return __uint_as_float((unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ unsigned long long to_fixed(float scaled) {
+    return (unsigned long long)(__double_as_longlong((double)scaled + kMagicD) - kMagicBitsD);
+}
+__device__ __forceinline__ float from_fixed(unsigned long long v, float inv_scale) {
+    return (float)((double)(long long)v * (double)inv_scale);
+}
+
+template <bool DO_G2P, bool DO_P2G>
+__global__ __launch_bounds__(kWG, 3) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
     __shared__ float tv[3][kTN];  // grid velocities of the tile (G2P source)
-    __shared__ float ta[4][kTN];  // (m*v.xyz, m) accumulated by this workgroup (P2G target)
+    __shared__ unsigned long long ta[4][kTN];  // (m*v.xyz, m) of this work item as scaled 64-bit integers (P2G target)
+    __shared__ float s_red[2][kWG / 64];
     const int4 it = S.items[blockIdx.x];
     const int tid = threadIdx.x;
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
@@ -436,25 +449,81 @@ __global__ __launch_bounds__(kWG) void mpm_block_kernel(MpmPtrs S, StepParams sp
                 g = S.gout[((size_t)gx * ng + gy) * ng + gz];
             tv[0][idx] = g.x; tv[1][idx] = g.y; tv[2][idx] = g.z;
         }
-        if (DO_P2G) { ta[0][idx] = 0.f; ta[1][idx] = 0.f; ta[2][idx] = 0.f; ta[3][idx] = 0.f; }
+        if (DO_P2G) { ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
     }
     __syncthreads();
-    for (int q = tid; q < it.z; q += kWG) particle_body<DO_G2P, DO_P2G, DBG>(S, sp, pms, it.y + q, ox, oy, oz, tv, ta);
-    if (DO_P2G && DBG != 1 && DBG != 2) {
-        __syncthreads();
+
+    ScatterIn in;
+    in.active = false;
+    if (tid < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + tid, ox, oy, oz, tv, in);
+    if (!DO_P2G) return;
+
+    // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----
+    Stencil st;
+    int b0 = -1;
+    if (in.active) {
+        st = make_stencil(in.x[0], in.x[1], in.x[2], S.inv_dx);
+        if (!stencil_inside(st, ng)) {
+            atomicAdd(S.oob, 1ull);
+            in.active = false;
+        } else {
+            const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
+            if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
+                b0 = (lx * kTS + ly) * kTS + lz;
+            } else {
+                atomicAdd(S.oob + 1, 1ull);
+                float mvAT[21];
 #pragma unroll
-        for (int idx = tid; idx < kTN; idx += kWG) {
-            const float mx = ta[0][idx], my = ta[1][idx], mz = ta[2][idx], m = ta[3][idx];
-            if (mx != 0.f || my != 0.f || mz != 0.f || m != 0.f) {
-                const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
-                float* cell = reinterpret_cast<float*>(S.gin + ((size_t)gx * ng + gy) * ng + gz);
-                unsafeAtomicAdd(cell + 0, mx);
-                unsafeAtomicAdd(cell + 1, my);
-                unsafeAtomicAdd(cell + 2, mz);
-                unsafeAtomicAdd(cell + 3, m);
+                for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) { mvAT[3 + q] = in.A.m[q]; mvAT[12 + q] = in.T.m[q]; }
+                p2g_scatter_global(S.gin, ng, st, mvAT, in.mass);
+                in.active = false;
             }
         }
     }
+    // ---- workgroup bounds -> power-of-two scales ----
+    float bp = 0.0f, bm = 0.0f;
+    if (in.active) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = fabsf(in.mv[a]) + 1.5f * (fabsf(in.A.m[3 * a]) + fabsf(in.A.m[3 * a + 1]) + fabsf(in.A.m[3 * a + 2])) +
+                            (fabsf(in.T.m[3 * a]) + fabsf(in.T.m[3 * a + 1]) + fabsf(in.T.m[3 * a + 2]));
+            bp = fmaxf(bp, r);
+        }
+        bm = in.mass;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bp = fmaxf(bp, __shfl_xor(bp, off, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+    }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
+    __syncthreads();
+    bp = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+    bm = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    const float sP = scale_for(bp), sM = scale_for(bm);
+
+    if (in.active) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { in.A.m[q] *= sP; in.T.m[q] *= sP; }
+        p2g_scatter(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
+            const int idx = b0 + (i * kTS + j) * kTS + k;
+            atomicAdd(&ta[0][idx], to_fixed(mom[0]));
+            atomicAdd(&ta[1][idx], to_fixed(mom[1]));
+            atomicAdd(&ta[2][idx], to_fixed(mom[2]));
+            atomicAdd(&ta[3][idx], to_fixed(m));
+        });
+    }
+    __syncthreads();
+    // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
+    const float iP = 1.0f / sP, iM = 1.0f / sM;
+    float4* dst = S.part + (size_t)blockIdx.x * kTN;
+#pragma unroll
+    for (int idx = tid; idx < kTN; idx += kWG)
+        dst[idx] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP), from_fixed(ta[3][idx], iM));
 }
 
 // ------------------------------------------------------------------ re-binning (counting sort by block)
@@ -494,7 +563,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(MpmPtrs S, int* __restri
 
 // exclusive scan of the block counts + the work list (<= kWG particles per item), one workgroup
 __global__ __launch_bounds__(1024) void bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets,
-                                                        int4* __restrict__ items, int* __restrict__ n_items, int nblocks, int cap) {
+                                                        int4* __restrict__ items, int2* __restrict__ blk_items,
+                                                        int* __restrict__ n_items, int nblocks, int cap) {
     __shared__ int s_cnt[1024], s_itm[1024];
     const int tid = threadIdx.x;
     const int per = (nblocks + 1023) / 1024;
@@ -514,6 +584,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const int* __restrict__ 
     for (int b = b0; b < b1; ++b) {
         const int cnt = counts[b];
         offsets[b] = c;
+        blk_items[b] = make_int2(i, (cnt + cap - 1) / cap);
         for (int j = 0; j < cnt; j += cap) items[i++] = make_int4(b, c + j, min(cap, cnt - j), 0);
         c += cnt;
     }
@@ -585,6 +656,85 @@ __device__ __forceinline__ void apply_bc(const BCDev& b, int ix, int iy, int iz,
             if (iz >= ng - padding && v[2] > 0.0f) v[2] = 0.0f;
         }
     }
+}
+
+// (m*v, m) of node (gx,gy,gz) = what slow-path particles added to gin + the tiles of the work items that cover the node.
+// A node with g = 4m + r along an axis lies in the tiles of blocks {m-1, m} (r < 3) or {m, m+1} (r = 3) on that axis:
+// 8 candidate blocks per node, all among the 27 neighbours of the node's own block.  The wave first fetches the 27
+// (first item, count) pairs with one load (lane i < 27), then every lane walks its 8 candidates in rounds so that the
+// 8 tile loads of a round are in flight together.  The order of the sum is fixed; every staged value is read once.
+__device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int Bx, int By, int Bz, int lx, int ly, int lz, float4 acc) {
+    const int lane = threadIdx.x & 63;
+    int2 mine = make_int2(0, 0);
+    if (lane < 27) {
+        const int bx = Bx + lane / 9 - 1, by = By + (lane / 3) % 3 - 1, bz = Bz + lane % 3 - 1;
+        if ((unsigned)bx < (unsigned)S.nbk && (unsigned)by < (unsigned)S.nbk && (unsigned)bz < (unsigned)S.nbk)
+            mine = S.blk_items[(bx * S.nbk + by) * S.nbk + bz];
+    }
+    if (__ballot(mine.y > 0) == 0ull) return acc;  // no particles anywhere near this block
+    const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
+    const float4* ptr[8];
+    int cnt[8];
+    int maxc = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int dx = ax + (c >> 2), dy = ay + ((c >> 1) & 1), dz = az + (c & 1);
+        const int src = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
+        const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
+        const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;  // this node inside that block's tile
+        ptr[c] = S.part + (size_t)first * kTN + (tx * kTS + ty) * kTS + tz;
+        cnt[c] = n;
+        maxc = max(maxc, n);
+    }
+    for (int r = 0; r < maxc; ++r) {
+        float4 q[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) q[c] = (r < cnt[c]) ? ptr[c][(size_t)r * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { acc.x += q[c].x; acc.y += q[c].y; acc.z += q[c].z; acc.w += q[c].w; }
+    }
+    return acc;
+}
+
+// One wave per 4x4x4 block of nodes: gather (above), grid_normalization_and_gravity, damping, BCs.
+__global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs) {
+    const int Bz = blockIdx.x % S.nbk, By = (blockIdx.x / S.nbk) % S.nbk, Bx = blockIdx.x / (S.nbk * S.nbk);
+    const int lx = threadIdx.x >> 4, ly = (threadIdx.x >> 2) & 3, lz = threadIdx.x & 3;
+    const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
+    const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
+    const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) {
+        g = S.gin[idx];
+        if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    g = gather_node(S, Bx, By, Bz, lx, ly, lz, g);
+    if (!inside) return;
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    if (g.w > 1e-15f) {
+        const float inv = 1.0f / g.w;
+        v[0] = g.x * inv + sp.dt * sp.g[0];
+        v[1] = g.y * inv + sp.dt * sp.g[1];
+        v[2] = g.z * inv + sp.dt * sp.g[2];
+    }
+    if (sp.do_damping) { v[0] *= sp.damping; v[1] *= sp.damping; v[2] *= sp.damping; }
+    for (int k = 0; k < bcs.n; ++k) apply_bc(bcs.bc[k], ix, iy, iz, S.ng, S.dx, sp.time, sp.dt, v);
+    S.gout[idx] = make_float4(v[0], v[1], v[2], 0.0f);
+}
+
+// export of grid_m / grid_v_in while a P2G is pending (tiles not yet consumed by the grid kernel)
+__global__ __launch_bounds__(64) void grid_export_pending_kernel(MpmPtrs S, float* __restrict__ out, int what) {
+    const int Bz = blockIdx.x % S.nbk, By = (blockIdx.x / S.nbk) % S.nbk, Bx = blockIdx.x / (S.nbk * S.nbk);
+    const int lx = threadIdx.x >> 4, ly = (threadIdx.x >> 2) & 3, lz = threadIdx.x & 3;
+    const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
+    const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
+    const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) g = S.gin[idx];
+    g = gather_node(S, Bx, By, Bz, lx, ly, lz, g);
+    if (!inside) return;
+    if (what == 0) out[idx] = g.w;
+    else { out[3 * idx] = g.x; out[3 * idx + 1] = g.y; out[3 * idx + 2] = g.z; }
 }
 
 __global__ __launch_bounds__(256) void mpm_grid_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int normalise) {
@@ -762,8 +912,9 @@ struct pixie_mpm {
     int n_items = 0;
     bool needs_sort = true;                  // positions changed behind the binning's back (or never binned)
     int resort_interval = 32, steps_since_sort = 0;
-    int item_cap = kWG;                      // particles per work item (multiple of kWG; one flush per item)
-    int debug_variant = 0;
+    int2* blk_items = nullptr;               // per block: (first work item, item count)
+    float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
+    bool pending_p2g = false;                // staged tiles not yet consumed by the grid kernel
     long n_sorts = 0;
     std::vector<void*> allocs;
     bool dirty_grid = false;                 // gin holds an un-consumed P2G (phase API)
@@ -794,7 +945,7 @@ void bind_rows(pixie_mpm* h) {
     S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
     S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n;
-    S.items = h->items;
+    S.items = h->items; S.part = h->part; S.blk_items = h->blk_items;
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -804,7 +955,7 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     const int n = S.n;
     PX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->nblocks * sizeof(int), st));
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->d_n_items, h->nblocks, h->item_cap);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, kWG);
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
     const int rows_per_y = 9;
     hipLaunchKernelGGL(bin_permute_kernel, dim3(cdiv(n, 256), cdiv(R_COUNT, rows_per_y)), dim3(256), 0, st,
@@ -887,10 +1038,7 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        if (h->debug_variant == 1) hipLaunchKernelGGL((mpm_block_kernel<true, true, 1>), grid, dim3(kWG), 0, st, h->S, sp, pms);
-        else if (h->debug_variant == 2) hipLaunchKernelGGL((mpm_block_kernel<true, true, 2>), grid, dim3(kWG), 0, st, h->S, sp, pms);
-        else if (h->debug_variant == 3) hipLaunchKernelGGL((mpm_block_kernel<true, true, 3>), grid, dim3(kWG), 0, st, h->S, sp, pms);
-        else hipLaunchKernelGGL((mpm_block_kernel<true, true>), grid, dim3(kWG), 0, st, h->S, sp, pms);
+        hipLaunchKernelGGL((mpm_block_kernel<true, true>), grid, dim3(kWG), 0, st, h->S, sp, pms);
     } else {
         if (g2p) {
             PModSet none{};
@@ -909,6 +1057,7 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         h->ev_particle.emplace_back(e0, e1);
     }
     PX_CHECK_HIP(hipGetLastError());
+    if (p2g) h->pending_p2g = true;
     return 0;
 }
 
@@ -927,10 +1076,14 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
         BCSet set{};
         set.n = (int)std::min<size_t>(kMaxBCPerLaunch, nbc - done);
         for (int k = 0; k < set.n; ++k) set.bc[k] = h->bcs_dev[done + k];
-        hipLaunchKernelGGL(mpm_grid_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, set, normalise);
+        if (normalise && h->pending_p2g)  // staged tiles of the last P2G + slow-path atomics in gin
+            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, sp, set);
+        else                              // nothing staged (or a further pass of BCs over gout)
+            hipLaunchKernelGGL(mpm_grid_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, set, normalise);
         done += set.n;
         normalise = 0;
     } while (done < nbc);
+    h->pending_p2g = false;
     if (e0) {
         PX_CHECK_HIP(hipEventRecord(e1, st));
         h->ev_grid.emplace_back(e0, e1);
@@ -975,6 +1128,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n);
     rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks);
     rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 1);
+    rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks); rc |= dev_alloc(h, &h->part, max_items * kTN);
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
     if (hipHostMalloc((void**)&h->h_n_items, sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
@@ -1034,7 +1188,10 @@ int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t cou
         const int k = (nm == "grid_m") ? 1 : 3;
         PX_REQUIRE(count == (int64_t)G * k, "get_field(%s): expected %lld scalars, got %lld", name, (long long)G * k, (long long)count);
         const float4* src = (nm == "grid_v_out") ? h->S.gout : h->S.gin;
-        hipLaunchKernelGGL(grid_export_kernel, dim3(cdiv(G, 256)), dim3(256), 0, st, src, (float*)d_dst, G, nm == "grid_m" ? 0 : 1);
+        if (nm != "grid_v_out" && h->pending_p2g)
+            hipLaunchKernelGGL(grid_export_pending_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, (float*)d_dst, nm == "grid_m" ? 0 : 1);
+        else
+            hipLaunchKernelGGL(grid_export_kernel, dim3(cdiv(G, 256)), dim3(256), 0, st, src, (float*)d_dst, G, nm == "grid_m" ? 0 : 1);
         PX_CHECK_HIP(hipGetLastError());
         return 0;
     }
@@ -1091,8 +1248,6 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
-    else if (k == "item_cap") { h->item_cap = std::max(kWG, ((int)value / kWG) * kWG); h->needs_sort = true; }
-    else if (k == "debug_variant") h->debug_variant = (int)value;
     else if (k == "resort_interval") h->resort_interval = (int)value;   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
     return 0;

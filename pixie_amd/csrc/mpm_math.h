@@ -177,6 +177,54 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
     sig[2] = u2[0] * B(0, 2) + u2[1] * B(1, 2) + u2[2] * B(2, 2);
 }
 
+// Rotation factor R of the polar decomposition F = R S by the scaled Newton iteration
+// R <- (g R + R^-T / g) / 2 (two Frobenius-scaled steps, then four plain ones): a third of the instructions and of
+// the dependency chain of svd3.  For det F > 0 it equals U V^T of the reference's wp.svd3 to fp32 roundoff, which is
+// all kirchoff_stress_FCR (mpm_utils.py:10-17) needs.  Returns false when the iteration has not settled (extreme
+// conditioning) or det F <= 0 (inverted element, where U V^T of the proper-rotation SVD is NOT the polar factor);
+// the caller then takes the svd3 route.
+PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
+    R = F;
+    float last = 1.0f;
+    float det = 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int it = 0; it < 6; ++it) {
+        Mat3 cof;
+        cof.m[0] = R.m[4] * R.m[8] - R.m[5] * R.m[7];
+        cof.m[1] = R.m[5] * R.m[6] - R.m[3] * R.m[8];
+        cof.m[2] = R.m[3] * R.m[7] - R.m[4] * R.m[6];
+        cof.m[3] = R.m[2] * R.m[7] - R.m[1] * R.m[8];
+        cof.m[4] = R.m[0] * R.m[8] - R.m[2] * R.m[6];
+        cof.m[5] = R.m[1] * R.m[6] - R.m[0] * R.m[7];
+        cof.m[6] = R.m[1] * R.m[5] - R.m[2] * R.m[4];
+        cof.m[7] = R.m[2] * R.m[3] - R.m[0] * R.m[5];
+        cof.m[8] = R.m[0] * R.m[4] - R.m[1] * R.m[3];
+        const float d = R.m[0] * cof.m[0] + R.m[1] * cof.m[1] + R.m[2] * cof.m[2];
+        if (it == 0) det = d;
+        const float inv_d = 1.0f / d;
+        float a = 0.5f, b = 0.5f * inv_d;  // R <- a R + b cof
+        if (it < 2) {
+            float nr = 0.0f, nc = 0.0f;
+            for (int i = 0; i < 9; ++i) { nr += R.m[i] * R.m[i]; nc += cof.m[i] * cof.m[i]; }
+            // g^2 = |R^-T|_F / |R|_F = |cof|_F / (|d| |R|_F)
+            const float g2 = sqrtf(nc / nr) * fabsf(inv_d);
+            const float g = sqrtf(g2);
+            a = 0.5f * g;
+            b = 0.5f * inv_d / g;
+        }
+        float delta = 0.0f;
+        for (int i = 0; i < 9; ++i) {
+            const float r = a * R.m[i] + b * cof.m[i];
+            delta = fmaxf(delta, fabsf(r - R.m[i]));
+            R.m[i] = r;
+        }
+        last = delta;
+    }
+    return det > 0.0f && last < 2e-6f;  // NaN (singular F) compares false
+}
+
 // ---------------------------------------------------------------- constitutive models
 struct MaterialScalars {  // MPMModelStruct scalars, warp_utils.py:24-36
     float alpha, hardening, xi, softening, plastic_viscosity;
@@ -299,8 +347,16 @@ PX_HD Mat3 kirchhoff_stress(int material, const Mat3& F, float mu, float lam, fl
     const float J = mat_det(F);
     Mat3 T;
     for (int i = 0; i < 9; ++i) T.m[i] = 0.0f;
+    Mat3 Rp;
     if (material == 6) {
         T = stress_water(J, bulk);
+    } else if (material == 0 && polar_rotation(F, Rp)) {
+        // fixed-corotated jelly: only the rotation is needed -- Newton polar instead of the full SVD
+        Mat3 D;
+        for (int i = 0; i < 9; ++i) D.m[i] = 2.0f * mu * (F.m[i] - Rp.m[i]);
+        T = mat_mul_bt(D, F);
+        const float iso = lam * J * (J - 1.0f);
+        T.m[0] += iso; T.m[4] += iso; T.m[8] += iso;
     } else if (material == 0 || material == 5 || material == 1 || material == 2 || material == 3) {
         Mat3 U, V;
         float sg[3];

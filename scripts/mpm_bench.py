@@ -22,10 +22,6 @@ def main():
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
     apply_scene(s, sc)
     s._set_scalar("resort_interval", resort)
-    if os.environ.get("PIXIE_ITEM_CAP"):
-        s._set_scalar("item_cap", int(os.environ["PIXIE_ITEM_CAP"]))
-    dbg = int(os.environ.get("PIXIE_DEBUG_VARIANT", "0"))
-    s._set_scalar("debug_variant", dbg)
     s.run(sc["dt"], 64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -38,7 +34,7 @@ def main():
     p_ms, g_ms, nl = s.kernel_times()
     s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
-    print(f"n={n} ng={ng} resort={resort} cap={os.environ.get('PIXIE_ITEM_CAP', 256)} dbg={dbg}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
+    print(f"n={n} ng={ng} resort={resort}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
           f"rebins {int(s._get_scalar('n_rebins'))} slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "

@@ -134,7 +134,7 @@ def test_device_svd_matches_oracle_convention():
     assert S[0, 0] > 0 and S[0, 1] > 0 and S[0, 2] < 0
 
 
-@pytest.mark.parametrize("material,scale,ys", [(0, 0.05, 0.0), (1, 0.08, 2.0e3), (1, 0.01, 1.0e9), (2, 0.05, 0.0), (3, 0.08, 1.0e3),
+@pytest.mark.parametrize("material,scale,ys", [(0, 0.05, 0.0), (0, 1e-3, 0.0), (0, 0.3, 0.0), (1, 0.08, 2.0e3), (1, 0.01, 1.0e9), (2, 0.05, 0.0), (3, 0.08, 1.0e3),
                                                (5, 0.08, 2.0e3), (6, 0.05, 0.0)])
 def test_device_stress_matches_oracle(material, scale, ys):
     """return_map_and_stress of mpm_math.h (host build) vs the C oracle's compute_stress on the same F_trial."""
