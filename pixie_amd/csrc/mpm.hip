@@ -300,7 +300,7 @@ struct ScatterIn {
 
 template <bool DO_G2P, bool DO_P2G>
 __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
-                                                int oz, float (*tv)[kTN], ScatterIn& out) {
+                                                int oz, const float4* tv, ScatterIn& out) {
     out.active = false;
     if (S.selection[p] != 0) return;
     const int n = S.n;
@@ -324,8 +324,8 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
             const int b0 = (lx * kTS + ly) * kTS + lz;
             g2p_gather(st, [&](int i, int j, int k, float g[3]) {
-                const int idx = b0 + (i * kTS + j) * kTS + k;
-                g[0] = tv[0][idx]; g[1] = tv[1][idx]; g[2] = tv[2][idx];
+                const float4 q = tv[b0 + (i * kTS + j) * kTS + k];  // one ds_read_b128 per node
+                g[0] = q.x; g[1] = q.y; g[2] = q.z;
             }, nv, B, G);
         } else {
             atomicAdd(S.oob + 1, 1ull);
@@ -430,9 +430,12 @@ __device__ __forceinline__ float from_fixed(unsigned long long v, float inv_scal
     return (float)((double)(long long)v * (double)inv_scale);
 }
 
+#ifndef PX_MPM_WAVES
+#define PX_MPM_WAVES 3
+#endif
 template <bool DO_G2P, bool DO_P2G>
-__global__ __launch_bounds__(kWG, 3) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
-    __shared__ float tv[3][kTN];  // grid velocities of the tile (G2P source)
+__global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
+    __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
     __shared__ unsigned long long ta[4][kTN];  // (m*v.xyz, m) of this work item as scaled 64-bit integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
     const int4 it = S.items[blockIdx.x];
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(kWG, 3) void mpm_block_kernel(MpmPtrs S, StepParams
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng)
                 g = S.gout[((size_t)gx * ng + gy) * ng + gz];
-            tv[0][idx] = g.x; tv[1][idx] = g.y; tv[2][idx] = g.z;
+            tv[idx] = g;
         }
         if (DO_P2G) { ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
     }
@@ -595,6 +598,48 @@ __global__ __launch_bounds__(256) void bin_order_kernel(const int* __restrict__ 
                                                         const int* __restrict__ offsets, int* __restrict__ order, int n) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < n) order[offsets[keys[p]] + rank[p]] = p;
+}
+
+// Order inside a block: round-robin over its 64 cells -- position = (rank within the cell, cell).  Consecutive lanes of
+// the block kernel then sit in consecutive cells, so the 27 same-offset LDS accesses of a wave (G2P reads and P2G
+// ds_add_u64) hit distinct nodes in distinct banks instead of colliding 3-4 ways as they do in arrival order.
+// One workgroup per block; `order` holds the block-contiguous listing, `order2` receives the final one.
+__device__ __forceinline__ int cell_in_block(const MpmPtrs& S, int p) {
+    int c = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int base = (int)(S.x[d * S.n + p] * S.inv_dx - 0.5f);
+        base = max(0, min(base, S.ng - 3));
+        c = c * kBS + (base & (kBS - 1));
+    }
+    return c;
+}
+__global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                              const int* __restrict__ order, int* __restrict__ cellk,
+                                                              int* __restrict__ rank, int* __restrict__ order2) {
+    __shared__ int cc[kBS * kBS * kBS];
+    const int b = blockIdx.x;
+    const int cnt = counts[b];
+    if (cnt == 0) return;
+    const int off = offsets[b];
+    if (threadIdx.x < kBS * kBS * kBS) cc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+        const int p = order[off + t];
+        const int c = cell_in_block(S, p);
+        cellk[off + t] = c;
+        rank[off + t] = atomicAdd(&cc[c], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+        const int c = cellk[off + t], r = rank[off + t];
+        int pos = 0;
+        for (int k = 0; k < kBS * kBS * kBS; ++k) {
+            const int n = cc[k];
+            pos += min(n, r) + ((k < c && n > r) ? 1 : 0);
+        }
+        order2[off + pos] = order[off + t];
+    }
 }
 
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
@@ -906,7 +951,7 @@ struct pixie_mpm {
     int cur = 0;
     // re-binning scratch
     int nblocks = 0;
-    int *keys = nullptr, *rank = nullptr, *counts = nullptr, *offsets = nullptr, *order = nullptr, *d_n_items = nullptr;
+    int *keys = nullptr, *rank = nullptr, *counts = nullptr, *offsets = nullptr, *order = nullptr, *order2 = nullptr, *d_n_items = nullptr;
     int4* items = nullptr;
     int* h_n_items = nullptr;                // pinned
     int n_items = 0;
@@ -957,9 +1002,12 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, kWG);
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
+    // keys/rank are free again: reuse them as the local kernel's scratch
+    hipLaunchKernelGGL(bin_local_order_kernel, dim3((unsigned)h->nblocks), dim3(256), 0, st, S, h->counts, h->offsets, h->order, h->keys,
+                       h->rank, h->order2);
     const int rows_per_y = 9;
     hipLaunchKernelGGL(bin_permute_kernel, dim3(cdiv(n, 256), cdiv(R_COUNT, rows_per_y)), dim3(256), 0, st,
-                       h->words[h->cur], h->words[h->cur ^ 1], h->order, n, rows_per_y);
+                       h->words[h->cur], h->words[h->cur ^ 1], h->order2, n, rows_per_y);
     PX_CHECK_HIP(hipGetLastError());
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, sizeof(int), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipStreamSynchronize(st));
@@ -1125,7 +1173,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
     rc |= dev_alloc(h, &S.gin, G); rc |= dev_alloc(h, &S.gout, G);
     rc |= dev_alloc(h, &S.oob, 2);
-    rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n);
+    rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n); rc |= dev_alloc(h, &h->order2, n);
     rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks);
     rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 1);
     rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks); rc |= dev_alloc(h, &h->part, max_items * kTN);
