@@ -145,88 +145,109 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     const uint4* wHi = A.w16 + kW16HeaderU4 + (size_t)kh * A.coutp + cout0 + l31;
     const uint4* wLo = wHi + plane;
 
-    const int items = 2 * A.CS;
+    constexpr int TAPS = KS * KS * KS;
     for (int c_base = 0; c_base < A.cin; c_base += 16) {
         __syncthreads();  // previous chunk fully consumed
-        // ---- stage the activation tile: 8 channels of one voxel per item -> one hi and one lo 16-byte LDS write ----
-        for (int it = tid; it < items; it += 256) {
-            const int kg = (it >= A.CS) ? 1 : 0;
-            int rem = it - kg * A.CS;
-            const int hz = fast_div16(rem, A.HYX, A.mHYX);
-            rem -= hz * A.HYX;
-            const int hy = fast_div16(rem, A.HX, A.mHX);
-            const int hx = rem - hy * A.HX;
-            const int lz = lz0 + hz, ly = ly0 + hy, lx = lx0 + hx;
-            f16x8 vh, vl;
+        // ---- stage the activation tile: one voxel x 16 channels per item, two items per thread in flight ----
+        // (the channel index is uniform across the workgroup, so the per-channel prologue constants and the
+        //  in0/in1 selection are scalar; each thread issues its 32 + 4 loads before it touches any of them)
+        for (int v0 = tid; v0 < A.CS; v0 += 512) {
+            float val[2][16];
+            float gm[2], bt[2];
+            int sidx[2];
+            bool ok[2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { vh[j] = (_Float16)0.0f; vl[j] = (_Float16)0.0f; }
-            if ((unsigned)lz < (unsigned)A.LD && (unsigned)ly < (unsigned)A.LH && (unsigned)lx < (unsigned)A.LW) {
-                const int sidx = ((lz >> A.ups) * A.IH + (ly >> A.ups)) * A.IW + (lx >> A.ups);
-                const int cg0 = c_base + kg * 8;
-                const float* src = (cg0 < A.c0) ? (A.in0 + (size_t)cg0 * ISP) : (A.in1 + (size_t)(cg0 - A.c0) * ISP);
-                float val[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) val[j] = src[(size_t)j * ISP + sidx];
-                if (A.pro_a) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) val[j] = val[j] * A.pro_a[cg0 + j] + A.pro_b[cg0 + j];
-                }
-                if (A.gamma) {
-                    const float gm = A.gamma[sidx], bt = A.beta[sidx];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) val[j] = val[j] * gm + bt;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float s = act16(val[j], A.act) * sx;
-                    const _Float16 h = (_Float16)s;
-                    vh[j] = h;
-                    vl[j] = (_Float16)(s - (float)h);
-                }
+            for (int u = 0; u < 2; ++u) {
+                const int vox = v0 + u * 256;
+                int rem = vox;
+                const int hz = fast_div16(rem, A.HYX, A.mHYX);
+                rem -= hz * A.HYX;
+                const int hy = fast_div16(rem, A.HX, A.mHX);
+                const int hx = rem - hy * A.HX;
+                const int lz = lz0 + hz, ly = ly0 + hy, lx = lx0 + hx;
+                ok[u] = vox < A.CS && (unsigned)lz < (unsigned)A.LD && (unsigned)ly < (unsigned)A.LH && (unsigned)lx < (unsigned)A.LW;
+                sidx[u] = ok[u] ? ((lz >> A.ups) * A.IH + (ly >> A.ups)) * A.IW + (lx >> A.ups) : 0;
             }
-            ldsHi[it] = __builtin_bit_cast(uint4, vh);
-            ldsLo[it] = __builtin_bit_cast(uint4, vl);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int cg = c_base + j;
+                    const float* src = (cg < A.c0) ? (A.in0 + (size_t)cg * ISP) : (A.in1 + (size_t)(cg - A.c0) * ISP);
+                    val[u][j] = ok[u] ? src[sidx[u]] : 0.0f;
+                }
+                gm[u] = 1.0f; bt[u] = 0.0f;
+                if (A.gamma && ok[u]) { gm[u] = A.gamma[sidx[u]]; bt[u] = A.beta[sidx[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int vox = v0 + u * 256;
+                if (vox >= A.CS) continue;
+                f16x8 vh[2], vl[2];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float t = val[u][j];
+                    if (A.pro_a) t = t * A.pro_a[c_base + j] + A.pro_b[c_base + j];
+                    t = t * gm[u] + bt[u];
+                    const float sc = ok[u] ? act16(t, A.act) * sx : 0.0f;   // zero padding AFTER the activation
+                    const _Float16 h = (_Float16)sc;
+                    vh[j >> 3][j & 7] = h;
+                    vl[j >> 3][j & 7] = (_Float16)(sc - (float)h);
+                }
+                ldsHi[vox] = __builtin_bit_cast(uint4, vh[0]);
+                ldsHi[A.CS + vox] = __builtin_bit_cast(uint4, vh[1]);
+                ldsLo[vox] = __builtin_bit_cast(uint4, vl[0]);
+                ldsLo[A.CS + vox] = __builtin_bit_cast(uint4, vl[1]);
+            }
         }
         __syncthreads();
-        // ---- MFMA over the taps of this 16-channel chunk ----
+        // ---- MFMA over the taps of this 16-channel chunk; the A fragments of tap t+1 are fetched during tap t ----
         const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
         const uint4* wl = wLo + (size_t)(c_base >> 3) * A.coutp;
+        f16x8 ah[MB], al[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            ah[mb] = __builtin_bit_cast(f16x8, wh[mb * 32]);
+            al[mb] = __builtin_bit_cast(f16x8, wl[mb * 32]);
+        }
 #pragma unroll 1
-        for (int dz = 0; dz < KS; ++dz) {
-#pragma unroll 1
-            for (int dy = 0; dy < KS; ++dy) {
+        for (int zy = 0; zy < KS * KS; ++zy) {
+            const int dz = zy / KS, dy = zy - dz * KS;
+            const int rowoff = (dz * A.HY + dy) * A.HX;
 #pragma unroll
-                for (int dx = 0; dx < KS; ++dx) {
-                    const int tap = (dz * KS + dy) * KS + dx;
-                    const int tapoff = (dz * A.HY + dy) * A.HX + dx;
-                    f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+            for (int dx = 0; dx < KS; ++dx) {
+                const int tap = zy * KS + dx;
+                const int nxt = (tap + 1 < TAPS) ? tap + 1 : tap;   // last tap: re-read itself (harmless)
+                f16x8 ahn[MB], aln[MB];
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        ah[mb] = __builtin_bit_cast(f16x8, wh[(size_t)tap * tap_stride + mb * 32]);
-                        al[mb] = __builtin_bit_cast(f16x8, wl[(size_t)tap * tap_stride + mb * 32]);
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        bh[nb] = __builtin_bit_cast(f16x8, ldsHi[voff[nb] + tapoff]);
-                        bl[nb] = __builtin_bit_cast(f16x8, ldsLo[voff[nb] + tapoff]);
-                    }
-                    // small terms first, then the leading term; every accumulator is revisited after MB*NB MFMAs
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                for (int mb = 0; mb < MB; ++mb) {
+                    ahn[mb] = __builtin_bit_cast(f16x8, wh[(size_t)nxt * tap_stride + mb * 32]);
+                    aln[mb] = __builtin_bit_cast(f16x8, wl[(size_t)nxt * tap_stride + mb * 32]);
                 }
+                f16x8 bh[NB], bl[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    bh[nb] = __builtin_bit_cast(f16x8, ldsHi[voff[nb] + rowoff + dx]);
+                    bl[nb] = __builtin_bit_cast(f16x8, ldsLo[voff[nb] + rowoff + dx]);
+                }
+                // small terms first, then the leading term; every accumulator is revisited after MB*NB MFMAs
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) { ah[mb] = ahn[mb]; al[mb] = aln[mb]; }
             }
         }
     }

@@ -48,9 +48,9 @@ constexpr int kWG = 256;                  // particles per work item / threads p
 // rows of the particle word array
 enum Row {
     R_X = 0, R_V = 3, R_F = 6, R_FT = 15, R_C = 24, R_VOL = 33, R_MASS, R_DENSITY, R_E, R_NU, R_MU, R_LAM, R_BULK, R_YS,
-    R_MATERIAL, R_SELECTION, R_PERM, R_COUNT
+    R_MATERIAL, R_SELECTION, R_PERM, R_XREF, R_COUNT = R_XREF + 3   // R_XREF: position at the last re-binning
 };
-static_assert(R_COUNT == 45, "row table");
+static_assert(R_COUNT == 48, "row table");
 
 struct MpmPtrs {
     int n, ng, nbk;   // particles, grid nodes per axis, blocks per axis
@@ -58,11 +58,15 @@ struct MpmPtrs {
     float *x, *v, *F, *Ft, *C;  // SoA: [3][n], [3][n], [9][n], [9][n], [9][n]
     float *vol, *mass, *density, *E, *nu, *mu, *lam, *bulk, *ys;
     int *material, *selection, *perm;
+    float* xref;                 // [3][n] positions at the last re-binning (drift measurement)
     float4 *gin, *gout;
     const int4* items;           // work list: (block id, first slot, count, 0)
     float4* part;                // [n_items][kTN]: (m*v.xyz, m) of each work item's tile, written by its P2G
     const int2* blk_items;       // per block: (first work item, number of work items)
-    unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles
+    int* blk_flags;              // per block: bit 0 = active (particles nearby), bit 1 = slow-path particles wrote into gin here
+    const int* active_list;      // the active blocks
+    unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles,
+                                 // [2] slow-path particles dropped because they had left every active block
 };
 
 struct StepParams {
@@ -258,8 +262,19 @@ __device__ __noinline__ void g2p_gather_global(const float4* __restrict__ gout, 
     for (int q = 0; q < 9; ++q) { nv9[3 + q] = B[q]; nv9[12 + q] = G[q]; }
 }
 
-__device__ __noinline__ void p2g_scatter_global(float4* gin, int ng, Stencil st, const float* mvAT /* mv[3], A[9], T[9] */, float mass) {
+__device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int nbk, int ng, Stencil st,
+                                                const float* mvAT /* mv[3], A[9], T[9] */, float mass) {
     const size_t r0 = ((size_t)st.base[0] * ng + st.base[1]) * ng + st.base[2];
+    // the 3x3x3 stencil touches at most 2 blocks per axis: tell the grid kernel they hold gin contributions.  The grid
+    // kernel only visits ACTIVE blocks (particles within one block at the last re-binning); a particle that has left
+    // all of them drifted >= 3 cells since then although the re-binning cadence is set to keep the drift below half a
+    // cell (rebin()) -- it is dropped and counted, like a particle that leaves the grid.
+    bool reachable = true;
+    for (int c = 0; c < 8; ++c) {
+        const int bx = (st.base[0] + 2 * (c >> 2)) / kBS, by = (st.base[1] + 2 * ((c >> 1) & 1)) / kBS, bz = (st.base[2] + 2 * (c & 1)) / kBS;
+        reachable = reachable && (atomicOr(&blk_flags[(bx * nbk + by) * nbk + bz], 2) & 1);
+    }
+    if (!reachable) return false;
 #pragma unroll 1
     for (int t = 0; t < 27; ++t) {
         const int i = t / 9, j = (t / 3) % 3, k = t % 3;
@@ -276,6 +291,7 @@ __device__ __noinline__ void p2g_scatter_global(float4* gin, int ng, Stencil st,
         }
         unsafeAtomicAdd(cell + 3, w * mass);
     }
+    return true;
 }
 
 // ------------------------------------------------------------------ fused block kernel
@@ -438,6 +454,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
     __shared__ unsigned long long ta[4][kTN];  // (m*v.xyz, m) of this work item as scaled 64-bit integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
+    __shared__ float4 tf[kTN];    // running fp32 tile of a multi-chunk work item
     const int4 it = S.items[blockIdx.x];
     const int tid = threadIdx.x;
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
@@ -456,77 +473,99 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
     }
     __syncthreads();
 
-    ScatterIn in;
-    in.active = false;
-    if (tid < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + tid, ox, oy, oz, tv, in);
-    if (!DO_P2G) return;
+    // One chunk of <= 256 particles per work item.  (Looping a workgroup over several chunks that share one tile --
+    // folding each chunk's integer sums into an fp32 tile tf -- halves the staged-tile traffic of large scenes, but
+    // the loop makes hipcc 7.2 spill ~190 VGPRs in this kernel and the rollout ran 2.5x slower; the code path is kept
+    // for a later round, the re-binning always emits single-chunk items.)
+    constexpr int nchunks = 1;
+    {
+        constexpr int ch = 0;
+        const int q = tid;
+        ScatterIn in;
+        in.active = false;
+        if (q < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + q, ox, oy, oz, tv, in);
+        if (!DO_P2G) return;
 
-    // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----
-    Stencil st;
-    int b0 = -1;
-    if (in.active) {
-        st = make_stencil(in.x[0], in.x[1], in.x[2], S.inv_dx);
-        if (!stencil_inside(st, ng)) {
-            atomicAdd(S.oob, 1ull);
-            in.active = false;
-        } else {
-            const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
-            if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
-                b0 = (lx * kTS + ly) * kTS + lz;
-            } else {
-                atomicAdd(S.oob + 1, 1ull);
-                float mvAT[21];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) { mvAT[3 + q] = in.A.m[q]; mvAT[12 + q] = in.T.m[q]; }
-                p2g_scatter_global(S.gin, ng, st, mvAT, in.mass);
+        // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----
+        Stencil st;
+        int b0 = -1;
+        if (in.active) {
+            st = make_stencil(in.x[0], in.x[1], in.x[2], S.inv_dx);
+            if (!stencil_inside(st, ng)) {
+                atomicAdd(S.oob, 1ull);
                 in.active = false;
+            } else {
+                const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
+                if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
+                    b0 = (lx * kTS + ly) * kTS + lz;
+                } else {
+                    atomicAdd(S.oob + 1, 1ull);
+                    float mvAT[21];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { mvAT[3 + k] = in.A.m[k]; mvAT[12 + k] = in.T.m[k]; }
+                    if (!p2g_scatter_global(S.gin, S.blk_flags, S.nbk, ng, st, mvAT, in.mass)) atomicAdd(S.oob + 2, 1ull);
+                    in.active = false;
+                }
             }
         }
-    }
-    // ---- workgroup bounds -> power-of-two scales ----
-    float bp = 0.0f, bm = 0.0f;
-    if (in.active) {
+        // ---- workgroup bounds -> power-of-two scales ----
+        float bp = 0.0f, bm = 0.0f;
+        if (in.active) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float r = fabsf(in.mv[a]) + 1.5f * (fabsf(in.A.m[3 * a]) + fabsf(in.A.m[3 * a + 1]) + fabsf(in.A.m[3 * a + 2])) +
-                            (fabsf(in.T.m[3 * a]) + fabsf(in.T.m[3 * a + 1]) + fabsf(in.T.m[3 * a + 2]));
-            bp = fmaxf(bp, r);
+            for (int a = 0; a < 3; ++a) {
+                const float r = fabsf(in.mv[a]) + 1.5f * (fabsf(in.A.m[3 * a]) + fabsf(in.A.m[3 * a + 1]) + fabsf(in.A.m[3 * a + 2])) +
+                                (fabsf(in.T.m[3 * a]) + fabsf(in.T.m[3 * a + 1]) + fabsf(in.T.m[3 * a + 2]));
+                bp = fmaxf(bp, r);
+            }
+            bm = in.mass;
         }
-        bm = in.mass;
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        bp = fmaxf(bp, __shfl_xor(bp, off, 64));
-        bm = fmaxf(bm, __shfl_xor(bm, off, 64));
-    }
-    if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
-    __syncthreads();
-    bp = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
-    bm = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
-    const float sP = scale_for(bp), sM = scale_for(bm);
+        for (int off = 32; off > 0; off >>= 1) {
+            bp = fmaxf(bp, __shfl_xor(bp, off, 64));
+            bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+        }
+        if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
+        __syncthreads();
+        bp = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+        bm = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+        const float sP = scale_for(bp), sM = scale_for(bm);
 
-    if (in.active) {
+        if (in.active) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
+            for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { in.A.m[q] *= sP; in.T.m[q] *= sP; }
-        p2g_scatter(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
-            const int idx = b0 + (i * kTS + j) * kTS + k;
-            atomicAdd(&ta[0][idx], to_fixed(mom[0]));
-            atomicAdd(&ta[1][idx], to_fixed(mom[1]));
-            atomicAdd(&ta[2][idx], to_fixed(mom[2]));
-            atomicAdd(&ta[3][idx], to_fixed(m));
-        });
+            for (int k = 0; k < 9; ++k) { in.A.m[k] *= sP; in.T.m[k] *= sP; }
+            p2g_scatter(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
+                const int idx = b0 + (i * kTS + j) * kTS + k;
+                atomicAdd(&ta[0][idx], to_fixed(mom[0]));
+                atomicAdd(&ta[1][idx], to_fixed(mom[1]));
+                atomicAdd(&ta[2][idx], to_fixed(mom[2]));
+                atomicAdd(&ta[3][idx], to_fixed(m));
+            });
+        }
+        __syncthreads();
+        const float iP = 1.0f / sP, iM = 1.0f / sM;
+        if (nchunks == 1) {
+            // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
+            float4* dst = S.part + (size_t)blockIdx.x * kTN;
+#pragma unroll
+            for (int idx = tid; idx < kTN; idx += kWG)
+                dst[idx] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
+                                       from_fixed(ta[3][idx], iM));
+        } else {
+#pragma unroll
+            for (int idx = tid; idx < kTN; idx += kWG) {
+                float4 v = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
+                                       from_fixed(ta[3][idx], iM));
+                if (ch > 0) { const float4 o = tf[idx]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                if (ch == nchunks - 1) S.part[(size_t)blockIdx.x * kTN + idx] = v;
+                else { tf[idx] = v; ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
-    const float iP = 1.0f / sP, iM = 1.0f / sM;
-    float4* dst = S.part + (size_t)blockIdx.x * kTN;
-#pragma unroll
-    for (int idx = tid; idx < kTN; idx += kWG)
-        dst[idx] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP), from_fixed(ta[3][idx], iM));
 }
 
 // ------------------------------------------------------------------ re-binning (counting sort by block)
@@ -544,10 +583,19 @@ __device__ __forceinline__ int block_of(const MpmPtrs& S, int p) {
 // key[p] = block of particle p; rank[p] = its arrival number inside the block.  Lanes of a wave that share a key
 // (the common case once the particles are binned) issue one atomic for the whole group.
 __global__ __launch_bounds__(256) void bin_count_kernel(MpmPtrs S, int* __restrict__ keys, int* __restrict__ rank,
-                                                        int* __restrict__ counts) {
+                                                        int* __restrict__ counts, unsigned* __restrict__ drift2_bits) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const bool valid = p < S.n;
     const int key = valid ? block_of(S, p) : -1;
+    {   // largest squared displacement since the last re-binning (drives the cadence, see rebin())
+        float d2 = 0.0f;
+        if (valid) {
+            for (int d = 0; d < 3; ++d) { const float e = S.x[d * S.n + p] - S.xref[d * S.n + p]; d2 += e * e; }
+            if (!(d2 < 3.0e38f)) d2 = 3.0e38f;
+        }
+        for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off, 64));
+        if ((threadIdx.x & 63) == 0 && d2 > __uint_as_float(*drift2_bits)) atomicMax(drift2_bits, __float_as_uint(d2));
+    }
     const int lane = threadIdx.x & 63;
     int my_rank = 0;
     unsigned long long todo = __ballot(valid);
@@ -642,6 +690,25 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
     }
 }
 
+// blk_flags bit 0 <- "one of my 27 neighbours holds particles", and the compact list of those ACTIVE blocks: the only
+// ones the grid kernel is launched for (workgroup dispatch alone costs ~10 us for the 27000 blocks of a 120^3 grid).
+__global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restrict__ counts, int* __restrict__ blk_flags,
+                                                              int* __restrict__ active_list, int* __restrict__ n_active, int nbk) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbk * nbk * nbk) return;
+    const int bz = b % nbk, by = (b / nbk) % nbk, bx = b / (nbk * nbk);
+    bool active = false;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int x = bx + dx, y = by + dy, z = bz + dz;
+                if ((unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk)
+                    active = active || counts[(x * nbk + y) * nbk + z] > 0;
+            }
+    blk_flags[b] = active ? 1 : 0;
+    if (active) active_list[atomicAdd(n_active, 1)] = b;
+}
+
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
 __global__ __launch_bounds__(256) void bin_permute_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
                                                           const int* __restrict__ order, int n, int rows_per_y) {
@@ -649,7 +716,10 @@ __global__ __launch_bounds__(256) void bin_permute_kernel(const unsigned* __rest
     if (q >= n) return;
     const int p = order[q];
     const int r0 = blockIdx.y * rows_per_y, r1 = min(r0 + rows_per_y, (int)R_COUNT);
-    for (int r = r0; r < r1; ++r) dst[(size_t)r * n + q] = src[(size_t)r * n + p];
+    for (int r = r0; r < r1; ++r) {
+        const int rs = (r >= R_XREF) ? (R_X + r - R_XREF) : r;   // xref <- x: positions at this re-binning
+        dst[(size_t)r * n + q] = src[(size_t)rs * n + p];
+    }
 }
 
 __global__ void iota_kernel(int* dst, int n) {
@@ -708,7 +778,8 @@ __device__ __forceinline__ void apply_bc(const BCDev& b, int ix, int iy, int iz,
 // 8 candidate blocks per node, all among the 27 neighbours of the node's own block.  The wave first fetches the 27
 // (first item, count) pairs with one load (lane i < 27), then every lane walks its 8 candidates in rounds so that the
 // 8 tile loads of a round are in flight together.  The order of the sum is fixed; every staged value is read once.
-__device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int Bx, int By, int Bz, int lx, int ly, int lz, float4 acc) {
+// lane i < 27 fetches (first item, count) of neighbour block i of block (Bx,By,Bz); other lanes get (0,0)
+__device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By, int Bz) {
     const int lane = threadIdx.x & 63;
     int2 mine = make_int2(0, 0);
     if (lane < 27) {
@@ -716,7 +787,9 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int Bx, int By, 
         if ((unsigned)bx < (unsigned)S.nbk && (unsigned)by < (unsigned)S.nbk && (unsigned)bz < (unsigned)S.nbk)
             mine = S.blk_items[(bx * S.nbk + by) * S.nbk + bz];
     }
-    if (__ballot(mine.y > 0) == 0ull) return acc;  // no particles anywhere near this block
+    return mine;
+}
+__device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
     const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
     const float4* ptr[8];
     int cnt[8];
@@ -731,29 +804,45 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int Bx, int By, 
         cnt[c] = n;
         maxc = max(maxc, n);
     }
-    for (int r = 0; r < maxc; ++r) {
-        float4 q[8];
+    // up to 4 items per block in one go: all 32 tile loads of a node are issued before the first is consumed
+    for (int r0 = 0; r0 < maxc; r0 += 4) {
+        float4 q[4][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) q[c] = (r < cnt[c]) ? ptr[c][(size_t)r * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { acc.x += q[c].x; acc.y += q[c].y; acc.z += q[c].z; acc.w += q[c].w; }
+            for (int c = 0; c < 8; ++c)
+                q[r][c] = (r0 + r < cnt[c]) ? ptr[c][(size_t)(r0 + r) * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
     }
     return acc;
 }
 
 // One wave per 4x4x4 block of nodes: gather (above), grid_normalization_and_gravity, damping, BCs.
-__global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs) {
-    const int Bz = blockIdx.x % S.nbk, By = (blockIdx.x / S.nbk) % S.nbk, Bx = blockIdx.x / (S.nbk * S.nbk);
+// A block is ACTIVE when one of its 27 neighbours (itself included) holds particles, or a slow-path particle wrote
+// into it (blk_flags).  Only active blocks are read by the next G2P (a tile reaches one block beyond its own), so
+// inactive blocks are skipped entirely (mode 0); their grid_v_out is brought up to date on demand (mode 1, used by
+// the grid_v_out export) with the parameters of the last update, which for a massless node is just the BCs on v = 0.
+__global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
+    const int blk = (mode == 0) ? S.active_list[blockIdx.x] : (int)blockIdx.x;
+    const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
+    const int flag = S.blk_flags[blk];  // bit 0: active (set at re-binning); bit 1: slow-path writes
+    if (mode == 1 && (flag & 1)) return;
+    const int2 mine = neighbour_items(S, Bx, By, Bz);
     const int lx = threadIdx.x >> 4, ly = (threadIdx.x >> 2) & 3, lz = threadIdx.x & 3;
     const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
     const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inside) {
-        g = S.gin[idx];
-        if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (mode == 0) {
+        if (flag & 2) {  // slow-path particles added fp32 atomics into gin here
+            if (inside) { g = S.gin[idx]; S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            if (threadIdx.x == 0) S.blk_flags[blk] = flag & 1;
+        }
+        g = gather_node(S, mine, lx, ly, lz, g);
     }
-    g = gather_node(S, Bx, By, Bz, lx, ly, lz, g);
     if (!inside) return;
     float v[3] = {0.0f, 0.0f, 0.0f};
     if (g.w > 1e-15f) {
@@ -776,7 +865,7 @@ __global__ __launch_bounds__(64) void grid_export_pending_kernel(MpmPtrs S, floa
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) g = S.gin[idx];
-    g = gather_node(S, Bx, By, Bz, lx, ly, lz, g);
+    g = gather_node(S, neighbour_items(S, Bx, By, Bz), lx, ly, lz, g);
     if (!inside) return;
     if (what == 0) out[idx] = g.w;
     else { out[3 * idx] = g.x; out[3 * idx + 1] = g.y; out[3 * idx + 2] = g.z; }
@@ -956,10 +1045,21 @@ struct pixie_mpm {
     int* h_n_items = nullptr;                // pinned
     int n_items = 0;
     bool needs_sort = true;                  // positions changed behind the binning's back (or never binned)
-    int resort_interval = 32, steps_since_sort = 0;
+    int resort_interval = 4, steps_since_sort = 0;  // starts cautious, doubles while the measured drift allows
+    bool xref_valid = false;
+    bool resort_auto = true;                 // adapt resort_interval to the observed drift (off once the caller sets it)
+    unsigned long long slow_at_rebin = 0;
     int2* blk_items = nullptr;               // per block: (first work item, item count)
+    int item_cap = kWG;                      // particles per work item: 256 (small problems) or 1024
+    bool pmods_were_active = false;
     float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
     bool pending_p2g = false;                // staged tiles not yet consumed by the grid kernel
+    int* blk_flags = nullptr;
+    int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
+    int n_active = 0;
+    bool gout_sparse = false;                // inactive blocks of gout are stale (refreshed on export)
+    StepParams last_grid_sp{};
+    std::vector<BCDev> last_grid_bcs;
     long n_sorts = 0;
     std::vector<void*> allocs;
     bool dirty_grid = false;                 // gin holds an un-consumed P2G (phase API)
@@ -989,8 +1089,8 @@ void bind_rows(pixie_mpm* h) {
     S.x = f + R_X * n; S.v = f + R_V * n; S.F = f + R_F * n; S.Ft = f + R_FT * n; S.C = f + R_C * n;
     S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
-    S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n;
-    S.items = h->items; S.part = h->part; S.blk_items = h->blk_items;
+    S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n;
+    S.items = h->items; S.part = h->part; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list;
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -998,9 +1098,15 @@ void bind_rows(pixie_mpm* h) {
 int rebin(pixie_mpm* h, hipStream_t st) {
     MpmPtrs& S = h->S;
     const int n = S.n;
+    h->item_cap = kWG;
     PX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->nblocks * sizeof(int), st));
-    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, kWG);
+    PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 2, 0, sizeof(int), st));
+    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts,
+                       reinterpret_cast<unsigned*>(h->d_n_items + 2));
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, h->item_cap);
+    PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 1, 0, sizeof(int), st));
+    hipLaunchKernelGGL(bin_mark_active_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->counts, h->blk_flags, h->active_list,
+                       h->d_n_items + 1, S.nbk);  // (rewrites every flag: no slow-path writes are pending here)
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
     // keys/rank are free again: reuse them as the local kernel's scratch
     hipLaunchKernelGGL(bin_local_order_kernel, dim3((unsigned)h->nblocks), dim3(256), 0, st, S, h->counts, h->offsets, h->order, h->keys,
@@ -1009,9 +1115,31 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     hipLaunchKernelGGL(bin_permute_kernel, dim3(cdiv(n, 256), cdiv(R_COUNT, rows_per_y)), dim3(256), 0, st,
                        h->words[h->cur], h->words[h->cur ^ 1], h->order2, n, rows_per_y);
     PX_CHECK_HIP(hipGetLastError());
-    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, sizeof(int), hipMemcpyDeviceToHost, st));
+    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 4, h->S.oob + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipStreamSynchronize(st));
-    h->n_items = *h->h_n_items;
+    h->n_items = h->h_n_items[0];
+    h->n_active = h->h_n_items[1];
+    // Cadence: the LDS tile tolerates one cell of drift, and the measured drift of the interval just finished
+    // predicts the next one -- aim at 0.4 cells, never more than double, and halve when > 0.1 % of the particles
+    // were on the slow path.  (The host enqueues substeps far ahead of the device, so this is the only feedback.)
+    if (h->resort_auto) {
+        unsigned long long slow_total;
+        memcpy(&slow_total, h->h_n_items + 4, sizeof slow_total);
+        const unsigned long long since = slow_total - h->slow_at_rebin;
+        h->slow_at_rebin = slow_total;
+        float d2;
+        memcpy(&d2, h->h_n_items + 2, sizeof d2);
+        const double drift_cells = sqrt((double)d2) * (double)S.inv_dx;
+        if (h->n_sorts > 0 && h->xref_valid) {
+            int k = h->resort_interval;
+            if (drift_cells > 0.0) k = (int)std::min<double>(2.0 * k, std::max<double>(0.25 * k, k * 0.4 / drift_cells));
+            else k = 2 * k;
+            if (since > (unsigned long long)n / 1000) k = std::min(k, h->resort_interval / 2);
+            h->resort_interval = std::max(2, std::min(k, 256));
+        }
+        h->xref_valid = true;
+    }
     h->cur ^= 1;
     bind_rows(h);
     h->needs_sort = false;
@@ -1061,7 +1189,8 @@ bool find_field(pixie_mpm* h, const std::string& name, FieldInfo* fi) {
 }
 
 int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st) {
-    if (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval))
+    // (never while staged tiles are waiting for the grid kernel: the work list they are indexed by must not change)
+    if (!h->pending_p2g && (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval)))
         if (rebin(h, st)) return 1;
     if (g2p) ++h->steps_since_sort;
     const int blocks = cdiv(h->S.n, 256);
@@ -1074,6 +1203,9 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
     // modifiers whose time window cannot contain this substep are dropped on the host
     ordered.erase(std::remove_if(ordered.begin(), ordered.end(),
                                  [&](const PModDev& m) { return !(sp.time >= m.start && sp.time < m.end); }), ordered.end());
+    if (h->resort_auto && !ordered.empty() && !h->pmods_were_active)   // a modifier switches on: velocities may jump
+        h->resort_interval = std::min(h->resort_interval, 4);
+    h->pmods_were_active = !ordered.empty();
     const bool fused_mods = ordered.size() <= (size_t)kMaxPModFused;
     if (fused_mods) {
         pms.n = (int)ordered.size();
@@ -1124,10 +1256,20 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
         BCSet set{};
         set.n = (int)std::min<size_t>(kMaxBCPerLaunch, nbc - done);
         for (int k = 0; k < set.n; ++k) set.bc[k] = h->bcs_dev[done + k];
-        if (normalise && h->pending_p2g)  // staged tiles of the last P2G + slow-path atomics in gin
-            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, sp, set);
-        else                              // nothing staged (or a further pass of BCs over gout)
+        if (normalise && h->pending_p2g && nbc <= (size_t)kMaxBCPerLaunch) {
+            // staged tiles of the last P2G + slow-path atomics in gin; blocks with nothing nearby are skipped
+            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)std::max(h->n_active, 1)), dim3(64), 0, st, h->S, sp, set, 0);
+            h->gout_sparse = true;
+            h->last_grid_sp = sp;
+            h->last_grid_bcs.assign(h->bcs_dev.begin(), h->bcs_dev.end());
+        } else if (normalise && h->pending_p2g) {  // more BCs than one launch carries: dense follow-up passes need every block
+            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)std::max(h->n_active, 1)), dim3(64), 0, st, h->S, sp, set, 0);
+            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, sp, set, 1);
+            h->gout_sparse = false;
+        } else {                          // nothing staged (or a further pass of BCs over gout)
             hipLaunchKernelGGL(mpm_grid_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, set, normalise);
+            if (normalise) h->gout_sparse = false;
+        }
         done += set.n;
         normalise = 0;
     } while (done < nbc);
@@ -1172,14 +1314,15 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     const size_t max_items = (n + kWG - 1) / kWG + std::min<size_t>((size_t)h->nblocks, n);
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
     rc |= dev_alloc(h, &S.gin, G); rc |= dev_alloc(h, &S.gout, G);
-    rc |= dev_alloc(h, &S.oob, 2);
+    rc |= dev_alloc(h, &S.oob, 3);
     rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n); rc |= dev_alloc(h, &h->order2, n);
     rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks);
-    rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 1);
-    rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks); rc |= dev_alloc(h, &h->part, max_items * kTN);
+    rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 4);
+    rc |= dev_alloc(h, &h->active_list, (size_t)h->nblocks);
+    rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks); rc |= dev_alloc(h, &h->blk_flags, (size_t)h->nblocks); rc |= dev_alloc(h, &h->part, max_items * kTN);
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
-    if (hipHostMalloc((void**)&h->h_n_items, sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
+    if (hipHostMalloc((void**)&h->h_n_items, 8 * sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
     bind_rows(h);
     hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.perm, n_particles);
     hipLaunchKernelGGL(identity_F_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.Ft, n_particles);  // :272-277
@@ -1217,7 +1360,7 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     FieldInfo fi;
     PX_REQUIRE(find_field(h, nm, &fi), "set_field: unknown field '%s'", name);
     PX_REQUIRE(count == (int64_t)n * fi.k, "set_field(%s): expected %lld scalars, got %lld", name, (long long)n * fi.k, (long long)count);
-    if (nm == "x") h->needs_sort = true;  // positions replaced: the block binning is stale
+    if (nm == "x") { h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval; }  // positions replaced: binning stale
     if (fi.is_int)
         hipLaunchKernelGGL(aos_to_soa_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)d_src, (int*)fi.ptr, n, fi.k, h->S.perm);
     else
@@ -1236,6 +1379,13 @@ int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t cou
         const int k = (nm == "grid_m") ? 1 : 3;
         PX_REQUIRE(count == (int64_t)G * k, "get_field(%s): expected %lld scalars, got %lld", name, (long long)G * k, (long long)count);
         const float4* src = (nm == "grid_v_out") ? h->S.gout : h->S.gin;
+        if (nm == "grid_v_out" && h->gout_sparse) {  // bring the skipped (massless, far from any particle) blocks up to date
+            BCSet set{};
+            set.n = (int)h->last_grid_bcs.size();
+            for (int k = 0; k < set.n; ++k) set.bc[k] = h->last_grid_bcs[k];
+            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, h->last_grid_sp, set, 1);
+            h->gout_sparse = false;
+        }
         if (nm != "grid_v_out" && h->pending_p2g)
             hipLaunchKernelGGL(grid_export_pending_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, (float*)d_dst, nm == "grid_m" ? 0 : 1);
         else
@@ -1296,7 +1446,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
-    else if (k == "resort_interval") h->resort_interval = (int)value;   // substeps between re-binnings (0 = only when positions are replaced)
+    else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
     return 0;
 }
@@ -1313,6 +1463,11 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
+    else if (k == "dropped_particles") {  // slow-path particles that had left every active block; synchronises the device
+        unsigned long long v = 0;
+        PX_CHECK_HIP(hipMemcpy(&v, h->S.oob + 2, sizeof v, hipMemcpyDeviceToHost));
+        *value = (double)v;
+    }
     else if (k == "slow_path_particles") {  // synchronises the device
         unsigned long long v = 0;
         PX_CHECK_HIP(hipMemcpy(&v, h->S.oob + 1, sizeof v, hipMemcpyDeviceToHost));
@@ -1428,10 +1583,10 @@ int pixie_mpm_export_R(pixie_mpm* h, float* d_R, void* stream) {
 
 int pixie_mpm_out_of_bounds(pixie_mpm* h, int64_t* count, void* stream) {
     PX_REQUIRE(h && count, "null argument");
-    unsigned long long v = 0;
-    PX_CHECK_HIP(hipMemcpyAsync(&v, h->S.oob, sizeof v, hipMemcpyDeviceToHost, as_stream(stream)));
+    unsigned long long v[3] = {0, 0, 0};
+    PX_CHECK_HIP(hipMemcpyAsync(v, h->S.oob, sizeof v, hipMemcpyDeviceToHost, as_stream(stream)));
     PX_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    *count = (int64_t)v;
+    *count = (int64_t)(v[0] + v[2]);  // left the grid + left every active block (see p2g_scatter_global)
     return 0;
 }
 

@@ -15,13 +15,14 @@ from pixie_amd.synthetic import apply_scene, mpm_ball_scene  # noqa: E402
 def main():
     n = int(sys.argv[1]); ng = int(sys.argv[2])
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-    resort = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    resort = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     sc = mpm_ball_scene(n, seed=0, n_grid=ng)
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
     apply_scene(s, sc)
-    s._set_scalar("resort_interval", resort)
+    if resort > 0:
+        s._set_scalar("resort_interval", resort)
     s.run(sc["dt"], 64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -123,6 +123,36 @@ def test_rollout_parity(hip_device, scenario, steps):
     assert h.out_of_bounds == 0
 
 
+def test_fast_particles_drift_controller_and_slow_path(hip_device):
+    """Particles crossing a cell every ~13 substeps (30 m/s, dx = 0.04, dt = 1e-4).  (a) Automatic cadence: the measured drift per interval sets the
+    next re-binning interval, no particle leaves its workgroup's LDS tile.  (b) Cadence pinned far too long: stencils
+    leave the tile, those particles go straight to HBM (slow path) -- results still match the oracle."""
+    sc = mpm_ball_scene(20000, seed=12, scenario="ball")
+    sc["params"] = dict(material="jelly", g=[0.0, 0.0, 0.0], E=2e5, nu=0.3, density=500.0)
+    sc["bcs"] = []
+    v0 = np.tile(np.array([[30.0, -12.0, 7.0]], np.float32), (20000, 1))
+    o = make_oracle(sc, "f64")
+    o.field("v")[:] = v0
+    o.run(sc["dt"], 60)
+    for pinned in (None, 20):   # 20 substeps = 1.5 cells of drift: past the one-cell margin of the tile, inside the active blocks
+        h = make_hip(sc)
+        h.set_field("v", v0)
+        if pinned:
+            h._set_scalar("resort_interval", pinned)
+        h.run(sc["dt"], 60)
+        slow, rebins = h._get_scalar("slow_path_particles"), h._get_scalar("n_rebins")
+        print(f"resort_interval {pinned or 'auto'}: slow-path particle-substeps {slow:.0f}, rebins {rebins:.0f}, "
+              f"dropped {h._get_scalar('dropped_particles'):.0f}, final interval {h._get_scalar('resort_interval'):.0f}")
+        if pinned:
+            assert slow > 0
+        else:
+            assert slow == 0 and rebins >= 6
+        assert h._get_scalar("dropped_particles") == 0 and h.out_of_bounds == 0
+        assert rel_l2(get(h, "x"), o.field("x")) < 1e-5
+        assert rel_l2(get(h, "v"), o.field("v")) < 1e-4
+        assert rel_l2(get(h, "F_trial").reshape(-1, 3, 3), o.field("F_trial")) < 1e-5
+
+
 def test_single_step_api_equals_batched(hip_device):
     """p2g2p(step, dt) called n times (3 launches each) == run(dt, n) (fused launches) up to atomics order."""
     sc = mpm_ball_scene(8000, seed=4, scenario="ball")
