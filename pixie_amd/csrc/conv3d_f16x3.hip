@@ -26,6 +26,11 @@
 //      the whole 64->64 3^3 layer is 442 KB), so LDS holds activations only and two workgroups fit per CU.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <type_traits>
+
 #include "../../include/pixie_hip.h"
 #include "common.h"
 
@@ -55,6 +60,7 @@ struct Conv16Args {
     int tiles_x, tiles_y, tiles_z, n_tiles;
     int HX, HY, HZ, HYX, CS;
     unsigned mHX, mHYX;
+    int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only
 };
 
 __device__ __forceinline__ int fast_div16(int n, int d, unsigned magic) {
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     constexpr int TAPS = KS * KS * KS;
     for (int c_base = 0; c_base < A.cin; c_base += 16) {
         __syncthreads();  // previous chunk fully consumed
+        if ((A.dbg & 2) && c_base > 0) goto staged;
         // ---- stage the activation tile: one voxel x 16 channels per item, two items per thread in flight ----
         // (the channel index is uniform across the workgroup, so the per-channel prologue constants and the
         //  in0/in1 selection are scalar; each thread issues its 32 + 4 loads before it touches any of them)
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
                 ldsLo[A.CS + vox] = __builtin_bit_cast(uint4, vl[1]);
             }
         }
+    staged:
         __syncthreads();
         // ---- MFMA over the taps of this 16-channel chunk; the A fragments of tap t+1 are fetched during tap t ----
         const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
                 const int tap = zy * KS + dx;
-                const int nxt = (tap + 1 < TAPS) ? tap + 1 : tap;   // last tap: re-read itself (harmless)
+                const int nxt = (A.dbg & 1) ? 0 : ((tap + 1 < TAPS) ? tap + 1 : tap);   // last tap: re-read itself (harmless)
                 f16x8 ahn[MB], aln[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
@@ -253,6 +261,288 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     }
 
     // ---- epilogue: unscale, + bias (+ residual); C/D layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const float inv = __uint_as_float(A.w16[0].x) * pow2i(-ex);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cout0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < A.cout) {
+                const float bv = A.bias ? A.bias[co] : 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (valid[nb]) {
+                        const size_t o = (size_t)co * OSP + ovox[nb];
+                        float val = acc[mb][nb][r] * inv + bv;
+                        if (A.residual) val += A.residual[o];
+                        A.out[o] = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENTAL, OFF BY DEFAULT (pixie_set_option("conv_pipeline", 1) / PIXIE_CONV_PIPE=1): bit-identical to the kernel
+// above, measured 1.74-1.89 ms against its 1.59 ms on the 64->64 3^3 128^3 layer (profiles/README.md) -- with one wave
+// per SIMD the compiler's interleaving of the staging VALU work between the MFMAs does not make up for losing the
+// second workgroup's overlap.  Kept, with its bit-identity test, as the starting point for a hand-scheduled version.
+//
+// Software-pipelined variant for the 3^3 layers that dominate the network (KS = 3): ONE workgroup per CU (one wave per
+// SIMD, so up to 512 registers per lane), the activation tile double-buffered in LDS (2 x 78 KB), and the staging of
+// chunk c+1 -- global loads, prologue, fp16 split, LDS writes -- spread over the first taps of chunk c, one 8-channel
+// unit per tap, so that it issues in the shadow of that tap's 24 MFMAs (32 cycles each on the SIMD's matrix pipe)
+// instead of stopping all four waves between chunks.  A fragments of tap t+1 are fetched during tap t.
+// The staging code is branch-free (template flags instead of null checks, clamped addresses and a dummy LDS slot
+// instead of bounds branches) so that it lives in the same basic block as the MFMAs and the scheduler can interleave it.
+struct StageRegs {
+    float val[8];
+    float gm, bt;
+    int slot;      // 16-byte LDS slot ([kg][voxel]) this unit is written to; the dummy slot when the unit does not exist
+    int kg;        // which half of the chunk's 16 channels
+    float sxe;     // input scale, or 0 outside the (logical) input volume: zero padding applied AFTER the activation
+};
+
+template <int MB, int NB, bool PRO, bool AFF, int ACT>
+__global__ __launch_bounds__(256, 1) void conv3d_f16x3_pipe_kernel(Conv16Args A) {
+    extern __shared__ uint4 smem16[];
+    constexpr int KS = 3, PAD = 1, TAPS = 27;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kh = lane >> 5;
+    const int l31 = lane & 31;
+
+    int t = blockIdx.x;
+    {
+        const int per = (A.n_tiles + 7) >> 3;
+        if ((A.n_tiles & 7) == 0) t = (t & 7) * per + (t >> 3);   // XCD-contiguous tile runs (see the kernel above)
+    }
+    const int tx = t % A.tiles_x; t /= A.tiles_x;
+    const int ty = t % A.tiles_y;
+    const int tz = t / A.tiles_y;
+    const int ox0 = tx * A.TX, oy0 = ty * A.TY, oz0 = tz * A.TZ;
+    const int cout0 = blockIdx.y * (MB * 32);
+    const int lx0 = ox0 - PAD, ly0 = oy0 - PAD, lz0 = oz0 - PAD;
+    const size_t ISP = (size_t)A.ID * A.IH * A.IW;
+    const size_t OSP = (size_t)A.OD * A.OH * A.OW;
+
+    int voff[NB];
+    int ovox[NB];
+    bool valid[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = (wave * NB + nb) * 32 + l31;
+        int x = j & (A.TX - 1);
+        int y = (j >> A.lTX) & (A.TY - 1);
+        int z = j >> (A.lTX + A.lTY);
+        const bool v = (z < A.TZ) && (ox0 + x < A.OW) && (oy0 + y < A.OH) && (oz0 + z < A.OD);
+        if (!v) { x = 0; y = 0; z = 0; }
+        voff[nb] = (z * A.HY + y) * A.HX + x + kh * A.CS;
+        ovox[nb] = ((oz0 + z) * A.OH + (oy0 + y)) * A.OW + ox0 + x;
+        valid[nb] = v;
+    }
+
+    float bound = A.in_bound;
+    if (A.amax0) {
+        bound = __uint_as_float(*A.amax0);
+        if (A.amax1) bound = fmaxf(bound, __uint_as_float(*A.amax1));
+    }
+    const int ex = scale_exponent(bound);
+    const float sx = pow2i(ex);
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+    const int KG = A.cin >> 3;
+    const size_t tap_stride = (size_t)KG * A.coutp;
+    const size_t plane = (size_t)TAPS * tap_stride;
+    const uint4* wHi = A.w16 + kW16HeaderU4 + (size_t)kh * A.coutp + cout0 + l31;
+    const uint4* wLo = wHi + plane;
+
+    const int nunits = 2 * A.CS;                 // 16-byte units per chunk: [kg 0..1][voxel]
+    const int upt = (nunits + 255) >> 8;         // units per thread (10 for the 32x4x4 tile)
+    const int half = 2 * A.CS + 1;               // uint4 per hi (or lo) plane of one buffer, + 1 dummy slot
+    const int bufsz = 2 * half;
+
+    // issue the loads of unit (k*256 + tid) of the chunk starting at channel c_base (no branches: see above)
+    auto stage_load = [&](int k, int c_base, StageRegs& r) {
+        const int it = k * 256 + tid;
+        const bool exists = it < nunits;
+        const int kg = (it >= A.CS) ? 1 : 0;
+        int rem = exists ? it - kg * A.CS : 0;
+        const int hz = (int)__umulhi((unsigned)rem, A.mHYX);   // HYX, HX >= 3 here: the magic multipliers are valid
+        rem -= hz * A.HYX;
+        const int hy = (int)__umulhi((unsigned)rem, A.mHX);
+        const int hx = rem - hy * A.HX;
+        const int lz = lz0 + hz, ly = ly0 + hy, lx = lx0 + hx;
+        const bool inb = exists && (unsigned)lz < (unsigned)A.LD && (unsigned)ly < (unsigned)A.LH && (unsigned)lx < (unsigned)A.LW;
+        r.sxe = inb ? sx : 0.0f;
+        r.slot = exists ? it : 2 * A.CS;
+        r.kg = kg;
+        // clamped coordinates: always a valid address, no branch; the value is multiplied by sxe = 0 when outside
+        const int cz = min(max(lz, 0), A.LD - 1), cy = min(max(ly, 0), A.LH - 1), cx = min(max(lx, 0), A.LW - 1);
+        const int sidx = ((cz >> A.ups) * A.IH + (cy >> A.ups)) * A.IW + (cx >> A.ups);
+        const int cg0 = c_base + kg * 8;
+        const float* src = (cg0 < A.c0) ? (A.in0 + (size_t)cg0 * ISP) : (A.in1 + (size_t)(cg0 - A.c0) * ISP);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.val[j] = src[(size_t)j * ISP + sidx];
+        if (AFF) { r.gm = A.gamma[sidx]; r.bt = A.beta[sidx]; }
+    };
+    // prologue + fp16 split + LDS write of a loaded unit into the buffer whose hi plane starts at `buf`
+    float pa[16], pb[16];   // per-channel prologue constants of the chunk being staged (uniform: scalar loads)
+    auto load_pro = [&](int c_base) {
+        if (PRO) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { pa[j] = A.pro_a[c_base + j]; pb[j] = A.pro_b[c_base + j]; }
+        }
+    };
+    auto stage_convert = [&](const StageRegs& r, f16x8& vh, f16x8& vl) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float tv = r.val[j];
+            if (PRO) tv = tv * (r.kg ? pa[8 + j] : pa[j]) + (r.kg ? pb[8 + j] : pb[j]);
+            if (AFF) tv = tv * r.gm + r.bt;
+            if (ACT == 1) tv = fmaxf(tv, 0.02f * tv);
+            if (ACT == 2) tv = tv / (1.0f + __expf(-tv));
+            const float sc = tv * r.sxe;
+            const _Float16 h = (_Float16)sc;
+            vh[j] = h;
+            vl[j] = (_Float16)(sc - (float)h);
+        }
+    };
+    auto stage_store = [&](const StageRegs& r, uint4* buf) {
+        f16x8 vh, vl;
+        stage_convert(r, vh, vl);
+        buf[r.slot] = __builtin_bit_cast(uint4, vh);
+        buf[half + r.slot] = __builtin_bit_cast(uint4, vl);
+    };
+
+    // ---- chunk 0 is staged up front ----
+    load_pro(0);
+    for (int k = 0; k < upt; ++k) {
+        StageRegs r;
+        stage_load(k, 0, r);
+        stage_store(r, smem16);
+    }
+    __syncthreads();
+
+    // one tap: [staging micro-step for the next chunk] + prefetch of the NEXT tap's A (L2) and B (LDS) fragments +
+    // 24 MFMAs on the current ones; the sched_group_barriers spread the memory ops and the VALU work between the MFMAs
+    f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+    constexpr int RING = 4;   // a unit's loads are consumed RING taps (~3000 cycles) after they were issued
+    StageRegs ring[RING];
+    auto tap_body = [&](auto stage_tag, int tap, int tapoff_next, const uint4* cur, uint4* nxt, const uint4* wh, const uint4* wl, int c_next,
+                        StageRegs& sr) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        StageRegs nw;
+        if (STAGE) stage_load(tap, c_next, nw);   // tap >= upt: nothing left, becomes the dummy unit
+        const int nt = (tap + 1 < TAPS) ? tap + 1 : tap;
+        f16x8 ahn[MB], aln[MB], bhn[NB], bln[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            ahn[mb] = __builtin_bit_cast(f16x8, wh[(size_t)nt * tap_stride + mb * 32]);
+            aln[mb] = __builtin_bit_cast(f16x8, wl[(size_t)nt * tap_stride + mb * 32]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bhn[nb] = __builtin_bit_cast(f16x8, cur[voff[nb] + tapoff_next]);
+            bln[nb] = __builtin_bit_cast(f16x8, cur[half + voff[nb] + tapoff_next]);
+        }
+        f16x8 vh, vl;
+        if (STAGE) stage_convert(sr, vh, vl);     // the unit loaded RING taps ago (first RING taps: the dummy unit)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+        if (STAGE) {
+            nxt[sr.slot] = __builtin_bit_cast(uint4, vh);
+            nxt[half + sr.slot] = __builtin_bit_cast(uint4, vl);
+            sr = nw;
+        }
+        // issue order: one MFMA, then what fits in its 32-cycle shadow
+#pragma unroll
+        for (int i = 0; i < 3 * MB * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one B-fragment read
+            if (i < 2 * MB + (STAGE ? 10 : 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one global load
+            __builtin_amdgcn_sched_group_barrier(0x002, STAGE ? 7 : 2, 0);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { ah[mb] = ahn[mb]; al[mb] = aln[mb]; }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { bh[nb] = bhn[nb]; bl[nb] = bln[nb]; }
+    };
+
+    const int nchunks = A.cin >> 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int c_base = c << 4;
+        const uint4* cur = smem16 + (c & 1) * bufsz;
+        uint4* nxt = smem16 + ((c & 1) ^ 1) * bufsz;
+        const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
+        const uint4* wl = wLo + (size_t)(c_base >> 3) * A.coutp;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            ah[mb] = __builtin_bit_cast(f16x8, wh[mb * 32]);
+            al[mb] = __builtin_bit_cast(f16x8, wl[mb * 32]);
+        }
+        // staged taps: unit k is loaded at tap k and written to LDS at tap k + RING; none for the last chunk
+        const int n_groups = (c + 1 < nchunks) ? (upt + RING + RING - 1) / RING : 0;
+        const int n_staged = min(n_groups * RING, TAPS / RING * RING);
+        if (n_staged) load_pro(c_base + 16);
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            ring[u].slot = 2 * A.CS; ring[u].sxe = 0.0f; ring[u].kg = 0; ring[u].gm = 1.0f; ring[u].bt = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ring[u].val[j] = 0.0f;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {   // B fragments of tap 0 (every later tap's are prefetched one tap ahead)
+            bh[nb] = __builtin_bit_cast(f16x8, cur[voff[nb]]);
+            bl[nb] = __builtin_bit_cast(f16x8, cur[half + voff[nb]]);
+        }
+        int dx = 0, dy = 0, tapoff = 0;
+        auto advance = [&](int tap) {   // LDS offset of the tap after `tap`
+            int tn = tapoff + 1;
+            if (++dx == KS) { dx = 0; tn += A.HX - KS; if (++dy == KS) { dy = 0; tn += (A.HY - KS) * A.HX; } }
+            return (tap == TAPS - 1) ? tapoff : tn;   // nothing after the last tap of a chunk: re-read (discarded)
+        };
+        // two separate loops (not one loop with a branch): the accumulators must not pass through a phi
+#pragma unroll 1
+        for (int t0 = 0; t0 < n_staged; t0 += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const int tn = advance(t0 + u);
+                tap_body(std::true_type{}, t0 + u, tn, cur, nxt, wh, wl, c_base + 16, ring[u]);
+                tapoff = tn;
+            }
+        }
+#pragma unroll 1
+        for (int tap = n_staged; tap < TAPS; ++tap) {
+            const int tn = advance(tap);
+            tap_body(std::false_type{}, tap, tn, cur, nxt, wh, wl, c_base + 16, ring[0]);
+            tapoff = tn;
+        }
+        __syncthreads();   // every wave is done reading `cur` and writing `nxt`
+    }
+
     const float inv = __uint_as_float(A.w16[0].x) * pow2i(-ex);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -337,6 +627,10 @@ static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStr
     return 0;
 }
 
+static int g_conv_dbg = 0;
+static bool g_conv_no_pipe = getenv("PIXIE_CONV_PIPE") == nullptr;   // measured slower on MI355X (see header): off by default
+void conv_set_pipe(bool on) { g_conv_no_pipe = !on; }
+
 // called by pixie_conv3d_forward (conv3d_mfma.hip) when the descriptor carries f16x2-packed weights
 int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     PX_REQUIRE(d->stride == 1, "f16x3 conv: stride must be 1");
@@ -355,6 +649,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     a.w16 = reinterpret_cast<const uint4*>(d->d_w16); a.bias = d->d_bias; a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     a.residual = d->d_residual; a.out = d->d_out;
     a.amax0 = d->d_in_amax0; a.amax1 = (d->c1 > 0) ? d->d_in_amax1 : nullptr; a.in_bound = d->in_bound;
+    a.dbg = g_conv_dbg;
 
     const long ovol = (long)a.OD * a.OH * a.OW;
     int MB = (a.coutp >= 64) ? 2 : 1;
@@ -380,6 +675,28 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     const size_t lds = (size_t)4 * a.CS * sizeof(uint4);
     PX_REQUIRE(lds <= 160 * 1024, "f16x3 conv: tile needs %zu B of LDS", lds);
     const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)));
+    // the software-pipelined kernel: 3^3, full 64 x 512 workgroup tile, double-buffered LDS must fit, > 1 chunk,
+    // and enough workgroups that one per CU still fills the chip
+    const bool no_pipe = g_conv_no_pipe;
+    const size_t lds_pipe = 2 * (lds + 2 * sizeof(uint4));   // two buffers, each with a dummy slot per plane
+    if (!no_pipe && d->ksize == 3 && MB == 2 && NB == 4 && lds_pipe <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 512) {
+        const bool pro = d->d_pro_a != nullptr, aff = d->d_gamma != nullptr;
+        const void* kern = nullptr;
+        if (pro && aff && d->act == 1) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, true, 1>);
+        else if (!pro && !aff && d->act == 0) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, false, false, 0>);
+        else if (pro && !aff && d->act == 2) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, false, 2>);
+        else if (pro && !aff && d->act == 0) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, false, 0>);
+        if (kern) {
+            static std::map<const void*, bool> attr_set;
+            if (!attr_set[kern]) {
+                PX_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set[kern] = true;
+            }
+            void* args[] = {const_cast<Conv16Args*>(&a)};
+            PX_CHECK_HIP(hipLaunchKernel(kern, grid, dim3(256), args, lds_pipe, st));
+            return 0;
+        }
+    }
 #define PX_CONV16_CASE(KS_, MB_, NB_) \
     if (d->ksize == KS_ && MB == MB_ && NB == NB_) return launch_f16x3<KS_, MB_, NB_>(a, lds, grid, st);
     PX_CONV16_CASE(3, 2, 4) PX_CONV16_CASE(3, 2, 2) PX_CONV16_CASE(3, 2, 1)
@@ -393,6 +710,13 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
 }  // namespace pixie
 
 using namespace pixie;
+
+extern "C" int pixie_set_option(const char* key, int value) {
+    PX_REQUIRE(key, "pixie_set_option: null key");
+    if (std::string(key) == "conv_pipeline") { conv_set_pipe(value != 0); return 0; }
+    if (std::string(key) == "conv_dbg") { g_conv_dbg = value; return 0; }
+    return set_error("pixie_set_option: unknown key '%s'", key);
+}
 
 extern "C" int64_t pixie_conv_packed16_bytes(int c_out, int c_in, int ksize) {
     if (c_out <= 0 || c_in <= 0 || c_in % 8 != 0 || (ksize != 1 && ksize != 3)) return 0;

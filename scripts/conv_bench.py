@@ -29,7 +29,10 @@ def main():
     ops = HipOps(dev)
     g = torch.Generator().manual_seed(0)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    for cins, cout, D, k, ups, prologue in SHAPES:
+    if os.environ.get("PIXIE_CONV_DBG"):
+        ops.lib.pixie_set_option(b"conv_dbg", int(os.environ["PIXIE_CONV_DBG"]))
+    nshapes = int(os.environ.get("PIXIE_CONV_NSHAPES", len(SHAPES)))
+    for cins, cout, D, k, ups, prologue in SHAPES[:nshapes]:
         cin = sum(cins)
         parts = [torch.randn((c, D, D, D), generator=g).to(dev) for c in cins]
         w = (torch.randn((cout, cin, k, k, k), generator=g) / (cin * k ** 3) ** 0.5).to(dev)

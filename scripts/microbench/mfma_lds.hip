@@ -1,0 +1,66 @@
+// Micro-benchmark: MFMA 32x32x16 f16 issue rate of a 4-wave workgroup running the conv kernel's tap loop
+// (24 MFMAs on 8 accumulators per tap) with the B fragments (a) kept in registers, (b) re-read from LDS every tap
+// (8 x ds_read_b128), (c) re-read from LDS one tap ahead (software prefetch), at 1 or 2 workgroups per CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int MODE, int OCC>
+__global__ __launch_bounds__(256, OCC) void k(const uint4* __restrict__ w, float* __restrict__ out, int taps, int lds_units) {
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < lds_units; i += 256) lds[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    __syncthreads();
+    f32x16 acc[2][4];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    f16x8 ah[2], al[2], bh[4], bl[4];
+    for (int m = 0; m < 2; ++m) { ah[m] = __builtin_bit_cast(f16x8, w[lane + m * 64]); al[m] = __builtin_bit_cast(f16x8, w[lane + 128 + m * 64]); }
+    int off = wave * 128 + lane;
+    for (int n = 0; n < 4; ++n) { bh[n] = __builtin_bit_cast(f16x8, lds[off + n * 32]); bl[n] = __builtin_bit_cast(f16x8, lds[off + n * 32 + 600]); }
+#pragma unroll 1
+    for (int t = 0; t < taps; ++t) {
+        f16x8 bhn[4], bln[4];
+        const int o2 = off + (t % 27) + 1;
+        if (MODE == 1) { for (int n = 0; n < 4; ++n) { bh[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32]); bl[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32 + 600]); } }
+        if (MODE == 2) { for (int n = 0; n < 4; ++n) { bhn[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32]); bln[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32 + 600]); } }
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        if (MODE == 2) { for (int n = 0; n < 4; ++n) { bh[n] = bhn[n]; bl[n] = bln[n]; } }
+    }
+    float s = 0.f;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE, int OCC>
+void run(const char* name, const uint4* w, float* out, int wgs, size_t lds_bytes) {
+    const int taps = 27 * 64;
+    auto kern = k<MODE, OCC>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, w, out, taps, 1300);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, w, out, taps, 1300);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flop = (double)wgs * 4 * taps * 24 * 2.0 * 32 * 32 * 16;
+    printf("%-44s %7.3f ms  %7.1f TFLOP/s f16 MFMA (%.1f %% of 2500)\n", name, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0);
+}
+
+int main() {
+    uint4* w; float* out;
+    CK(hipMalloc(&w, 4096 * 16)); CK(hipMemset(w, 0x3c, 4096 * 16)); CK(hipMalloc(&out, 4096 * 256 * 4));
+    run<0, 2>("B in registers, 2 WG/CU (78 KB LDS each)", w, out, 2048, 78 * 1024);
+    run<1, 2>("B from LDS each tap, 2 WG/CU", w, out, 2048, 78 * 1024);
+    run<2, 2>("B from LDS one tap ahead, 2 WG/CU", w, out, 2048, 78 * 1024);
+    run<0, 1>("B in registers, 1 WG/CU (156 KB LDS)", w, out, 1024, 156 * 1024);
+    run<1, 1>("B from LDS each tap, 1 WG/CU", w, out, 1024, 156 * 1024);
+    run<2, 1>("B from LDS one tap ahead, 1 WG/CU", w, out, 1024, 156 * 1024);
+    run<0, 2>("B in registers, 4 WG/CU (32 KB LDS each)", w, out, 4096, 32 * 1024);
+    run<1, 2>("B from LDS each tap, 4 WG/CU (32 KB)", w, out, 4096, 32 * 1024);
+    return 0;
+}

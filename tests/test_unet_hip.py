@@ -143,6 +143,57 @@ def test_conv3d_f16x3_dynamic_range(ops):
     assert per < 1e-5, per
 
 
+@pytest.mark.parametrize("variant", ["ln_leaky", "raw", "gn_silu", "gn_none", "concat_ln"])
+def test_conv3d_pipelined_kernel_is_bit_identical(ops, variant):
+    """The software-pipelined f16x3 kernel (one workgroup per CU, LDS double buffer, staging interleaved with the
+    MFMAs) against the plain f16x3 kernel on a 64^3 grid (512 workgroups, the smallest launch that selects it):
+    same MFMA order, so the outputs must agree bit for bit; and both against a float64 reference on sample voxels."""
+    from pixie_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    D = 64
+    cins = (64, 64) if variant == "concat_ln" else (64,)
+    cin = sum(cins)
+    parts = [torch.randn((c, D, D, D), generator=g) for c in cins]
+    w = torch.randn((64, cin, 3, 3, 3), generator=g) / np.sqrt(cin * 27)
+    b = torch.randn(64, generator=g)
+    pro = affine = None
+    act = 0
+    if variant in ("ln_leaky", "concat_ln"):
+        pro = (torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g))
+        affine = (1 + 0.1 * torch.randn((D, D, D), generator=g), 0.1 * torch.randn((D, D, D), generator=g))
+        act = 1
+    elif variant == "gn_silu":
+        pro = (torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)); act = 2
+    elif variant == "gn_none":
+        pro = (torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g))
+    dev = ops.device
+    to = lambda t: t.to(dev) if t is not None else None
+    dparts = [to(p) for p in parts]
+    kw = dict(pro=tuple(map(to, pro)) if pro else None, affine=tuple(map(to, affine)) if affine else None, act=act,
+              residual=dparts[0])
+    if pro is None:
+        kw["in_amax"] = _amax_slots(ops, dparts)
+    else:
+        kw["in_bound"] = float(_prologue_cpu(parts, pro, affine, act).abs().max())
+    w16 = ops.pack_conv16(to(w))
+    outs = []
+    for pipe in (1, 0):
+        assert lib.pixie_set_option(b"conv_pipeline", pipe) == 0
+        outs.append(ops.conv(dparts, None, to(b), 64, 3, w16=w16, **kw))
+    lib.pixie_set_option(b"conv_pipeline", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    # float64 spot check on a 6^3 corner block and a 6^3 interior block (halo and padding paths)
+    x = _prologue_cpu(parts, pro, affine, act).double()
+    xp = F.pad(x, (1, 1, 1, 1, 1, 1))
+    out = outs[0].cpu().double()
+    for z0, y0, x0 in ((0, 0, 0), (29, 30, 31), (58, 58, 58)):
+        ref = F.conv3d(xp[None, :, z0:z0 + 8, y0:y0 + 8, x0:x0 + 8], w.double(), b.double())[0] + parts[0][:, z0:z0 + 6, y0:y0 + 6, x0:x0 + 6].double()
+        got = out[:, z0:z0 + 6, y0:y0 + 6, x0:x0 + 6]
+        assert rel_l2(got.numpy(), ref.numpy()) < 2e-6
+
+
 def test_conv3d_residual_may_alias_output_and_is_deterministic(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn((64, 16, 16, 16), generator=g).to(ops.device)
