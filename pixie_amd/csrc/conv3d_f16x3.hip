@@ -81,16 +81,24 @@ __device__ __forceinline__ int scale_exponent(float bound) {
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
-template <int KS, int MB, int NB>
-__global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
+// WS is EXPERIMENTAL and OFF BY DEFAULT (pixie_set_option("conv_wave_specialised", 1) / PIXIE_CONV_WS=1): bit-identical,
+// but a single MFMA wave per SIMD sustains only about a third of the matrix pipe in this loop (its per-tap A-fragment
+// and B-fragment latencies are exposed), so the layer takes 1.95 ms instead of 1.54 ms.
+// WS ("wave-specialised", 512 threads, one workgroup per CU): waves 0-3 run the MFMA loop of chunk c out of one LDS
+// buffer while waves 4-7 -- one per SIMD, next to a compute wave -- stage chunk c+1 into the other, so the loads,
+// the prologue arithmetic and the LDS writes are scheduled by the hardware into the gaps of the matrix pipe instead
+// of stopping it between chunks.  Without WS (256 threads) two workgroups share a CU and overlap only by chance.
+template <int KS, int MB, int NB, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     extern __shared__ uint4 smem16[];
     constexpr int PAD = (KS == 3) ? 1 : 0;
-    uint4* ldsHi = smem16;                 // [2][CS]
-    uint4* ldsLo = smem16 + 2 * A.CS;      // [2][CS]
+    constexpr int NT = WS ? 512 : 256;
+    const int bufsz = 4 * A.CS;            // one buffer: hi[2][CS], lo[2][CS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) & 3;       // position among the 4 compute waves (loader waves never use it)
+    const bool loader = WS && tid >= 256;
     const int kh = lane >> 5;
     const int l31 = lane & 31;
 
@@ -152,20 +160,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     const uint4* wLo = wHi + plane;
 
     constexpr int TAPS = KS * KS * KS;
-    for (int c_base = 0; c_base < A.cin; c_base += 16) {
-        __syncthreads();  // previous chunk fully consumed
-        if ((A.dbg & 2) && c_base > 0) goto staged;
-        // ---- stage the activation tile: one voxel x 16 channels per item, two items per thread in flight ----
-        // (the channel index is uniform across the workgroup, so the per-channel prologue constants and the
-        //  in0/in1 selection are scalar; each thread issues its 32 + 4 loads before it touches any of them)
-        for (int v0 = tid; v0 < A.CS; v0 += 512) {
+    // ---- stage the 16-channel chunk starting at c_base into `buf`: one voxel x 16 channels per item, two items per
+    // thread in flight (the channel index is uniform across the stagers, so the per-channel prologue constants and
+    // the in0/in1 selection are scalar; each thread issues its 32 + 4 loads before it touches any of them)
+    auto stage_chunk = [&](int c_base, uint4* buf, int stid, int nthr) {
+        uint4* bHi = buf;
+        uint4* bLo = buf + 2 * A.CS;
+        for (int v0 = stid; v0 < A.CS; v0 += 2 * nthr) {
             float val[2][16];
             float gm[2], bt[2];
             int sidx[2];
             bool ok[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int vox = v0 + u * 256;
+                const int vox = v0 + u * nthr;
                 int rem = vox;
                 const int hz = fast_div16(rem, A.HYX, A.mHYX);
                 rem -= hz * A.HYX;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int vox = v0 + u * 256;
+                const int vox = v0 + u * nthr;
                 if (vox >= A.CS) continue;
                 f16x8 vh[2], vl[2];
 #pragma unroll
@@ -201,15 +209,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
                     vh[j >> 3][j & 7] = h;
                     vl[j >> 3][j & 7] = (_Float16)(sc - (float)h);
                 }
-                ldsHi[vox] = __builtin_bit_cast(uint4, vh[0]);
-                ldsHi[A.CS + vox] = __builtin_bit_cast(uint4, vh[1]);
-                ldsLo[vox] = __builtin_bit_cast(uint4, vl[0]);
-                ldsLo[A.CS + vox] = __builtin_bit_cast(uint4, vl[1]);
+                bHi[vox] = __builtin_bit_cast(uint4, vh[0]);
+                bHi[A.CS + vox] = __builtin_bit_cast(uint4, vh[1]);
+                bLo[vox] = __builtin_bit_cast(uint4, vl[0]);
+                bLo[A.CS + vox] = __builtin_bit_cast(uint4, vl[1]);
             }
         }
-    staged:
-        __syncthreads();
-        // ---- MFMA over the taps of this 16-channel chunk; the A fragments of tap t+1 are fetched during tap t ----
+    };
+    // ---- MFMA over the taps of one chunk; the A fragments of tap t+1 are fetched during tap t ----
+    auto mfma_chunk = [&](int c_base, const uint4* buf) {
+        const uint4* ldsHi = buf;
+        const uint4* ldsLo = buf + 2 * A.CS;
         const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
         const uint4* wl = wLo + (size_t)(c_base >> 3) * A.coutp;
         f16x8 ah[MB], al[MB];
@@ -257,6 +267,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) { ah[mb] = ahn[mb]; al[mb] = aln[mb]; }
             }
+        }
+    };
+
+    if (WS) {
+        stage_chunk(0, smem16, tid, NT);     // everybody stages chunk 0
+        __syncthreads();
+        int par = 0;
+        for (int c_base = 0; c_base < A.cin; c_base += 16, par ^= 1) {
+            if (loader) {
+                if (c_base + 16 < A.cin) stage_chunk(c_base + 16, smem16 + (par ^ 1) * bufsz, tid - 256, 256);
+            } else {
+                mfma_chunk(c_base, smem16 + par * bufsz);
+            }
+            __syncthreads();   // buffer `par` fully consumed, buffer `par ^ 1` fully written
+        }
+        if (loader) return;
+    } else {
+        for (int c_base = 0; c_base < A.cin; c_base += 16) {
+            __syncthreads();  // previous chunk fully consumed
+            if (!((A.dbg & 2) && c_base > 0)) stage_chunk(c_base, smem16, tid, NT);
+            __syncthreads();
+            mfma_chunk(c_base, smem16);
         }
     }
 
@@ -614,20 +646,21 @@ static unsigned magic_of16(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000
 static int ilog2_16(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static int pow2_le16(int v, int cap) { int p = 1; while (p * 2 <= v && p * 2 <= cap) p *= 2; return p; }
 
-template <int KS, int MB, int NB>
+template <int KS, int MB, int NB, bool WS = false>
 static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStream_t st) {
-    auto kern = conv3d_f16x3_kernel<KS, MB, NB>;
+    auto kern = conv3d_f16x3_kernel<KS, MB, NB, WS>;
     static bool attr_set = false;
     if (!attr_set) {
         PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WS ? 512 : 256), lds_bytes, st, a);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 static int g_conv_dbg = 0;
+static bool g_conv_ws = getenv("PIXIE_CONV_WS") != nullptr;   // measured slower on MI355X (1.95 vs 1.54 ms): off by default
 static bool g_conv_no_pipe = getenv("PIXIE_CONV_PIPE") == nullptr;   // measured slower on MI355X (see header): off by default
 void conv_set_pipe(bool on) { g_conv_no_pipe = !on; }
 
@@ -697,6 +730,10 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
             return 0;
         }
     }
+    // wave-specialised variant: the full 64 x 512 tile of a 3^3 layer, both LDS buffers fit, and at least one
+    // workgroup per CU
+    if (g_conv_ws && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
+        return launch_f16x3<3, 2, 4, true>(a, 2 * lds, grid, st);
 #define PX_CONV16_CASE(KS_, MB_, NB_) \
     if (d->ksize == KS_ && MB == MB_ && NB == NB_) return launch_f16x3<KS_, MB_, NB_>(a, lds, grid, st);
     PX_CONV16_CASE(3, 2, 4) PX_CONV16_CASE(3, 2, 2) PX_CONV16_CASE(3, 2, 1)
@@ -715,6 +752,7 @@ extern "C" int pixie_set_option(const char* key, int value) {
     PX_REQUIRE(key, "pixie_set_option: null key");
     if (std::string(key) == "conv_pipeline") { conv_set_pipe(value != 0); return 0; }
     if (std::string(key) == "conv_dbg") { g_conv_dbg = value; return 0; }
+    if (std::string(key) == "conv_wave_specialised") { g_conv_ws = value != 0; return 0; }
     return set_error("pixie_set_option: unknown key '%s'", key);
 }
 

@@ -144,10 +144,11 @@ def test_conv3d_f16x3_dynamic_range(ops):
 
 
 @pytest.mark.parametrize("variant", ["ln_leaky", "raw", "gn_silu", "gn_none", "concat_ln"])
-def test_conv3d_pipelined_kernel_is_bit_identical(ops, variant):
-    """The software-pipelined f16x3 kernel (one workgroup per CU, LDS double buffer, staging interleaved with the
-    MFMAs) against the plain f16x3 kernel on a 64^3 grid (512 workgroups, the smallest launch that selects it):
-    same MFMA order, so the outputs must agree bit for bit; and both against a float64 reference on sample voxels."""
+def test_conv3d_kernel_variants_are_bit_identical(ops, variant):
+    """The three f16x3 kernels for the dominant 3^3 layers -- plain (2 workgroups per CU; the default), experimental
+    wave-specialised (4 MFMA waves + 4 staging waves, LDS double buffer) and experimental software-pipelined -- on a 64^3 grid
+    (512 workgroups): same MFMA order, so the outputs must agree bit for bit; and against a float64 reference on
+    sample blocks (corner, interior: halo and padding paths)."""
     from pixie_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(17)
@@ -178,12 +179,14 @@ def test_conv3d_pipelined_kernel_is_bit_identical(ops, variant):
         kw["in_bound"] = float(_prologue_cpu(parts, pro, affine, act).abs().max())
     w16 = ops.pack_conv16(to(w))
     outs = []
-    for pipe in (1, 0):
+    for ws, pipe in ((1, 0), (0, 1), (0, 0)):   # wave-specialised (default), experimental pipelined, plain
+        assert lib.pixie_set_option(b"conv_wave_specialised", ws) == 0
         assert lib.pixie_set_option(b"conv_pipeline", pipe) == 0
         outs.append(ops.conv(dparts, None, to(b), 64, 3, w16=w16, **kw))
+    lib.pixie_set_option(b"conv_wave_specialised", 0)
     lib.pixie_set_option(b"conv_pipeline", 0)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
     # float64 spot check on a 6^3 corner block and a 6^3 interior block (halo and padding paths)
     x = _prologue_cpu(parts, pro, affine, act).double()
     xp = F.pad(x, (1, 1, 1, 1, 1, 1))
