@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mpm-substeps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mpm", action="store_true")
+    ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
     ap.add_argument("--conv-precision", choices=["f16x3", "f32"], default=None,
                     help="f16x3 (default): fp32 operands split into fp16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate; "
                          "f32: exact-fp32 MFMA everywhere")
@@ -146,7 +147,9 @@ def bench_unet(args, rank, world, device):
             # achieved = ALGORITHMIC (fp32-equivalent) FLOP/s; the kernel issues 3 f16 MFMAs per algorithmic product,
             # so the matrix pipe is doing 3x that.  peak = dense f16 MFMA peak; frac = achieved/peak (conservative).
             roof = {"bound": "mfma", "kernel": "conv3d_f16x3_kernel<3,2,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
-                    "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                    "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
+                    "traffic": (load_traffic().get("conv_64_64_128") or {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": "profiles/pmc_traffic.json" if load_traffic().get("conv_64_64_128") else None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl,
                     "mfma_issue_ratio": 3, "mfma_hw_tflops": round(3 * ach, 1), "mfma_hw_frac": round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
                     "vs_exact_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3)}
@@ -159,36 +162,54 @@ def bench_unet(args, rank, world, device):
                 conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(args.steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]})
 
 
-def bench_mpm(args, rank, world, device):
+def load_traffic():
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE in
+    separate passes, corrected with calibration kernels of the same access widths, scripts/gpu_pmc.sh).  PMC counters
+    cannot be collected from inside this process, so `traffic` is the profile's reading for the same kernel + shape."""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
+def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag):
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
-    sc = mpm_ball_scene(args.particles, seed=rank, n_grid=args.n_grid)
+    sc = mpm_ball_scene(particles, seed=rank, n_grid=n_grid)
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
     apply_scene(s, sc)
-    s.run(sc["dt"], 50)  # warm-up
+    s.run(sc["dt"], 50)  # warm-up (includes the cautious first re-binning intervals)
     barrier_sync(world)
     t0 = time.perf_counter()
-    s.run(sc["dt"], args.mpm_substeps)
+    s.run(sc["dt"], substeps)
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, device)
-    # separate short pass with per-launch HIP events on the launch stream for the roofline of the fused particle kernel
+    # separate short pass with per-launch HIP events on the launch stream for the roofline of the fused block kernel
     s.set_profile(True)
     s.run(sc["dt"], 200)
     torch.cuda.synchronize()
     p_ms, g_ms, n_launch = s.kernel_times()
     s.set_profile(False)
-    alg_bytes = 212.0 * args.particles + 44.0 * args.n_grid ** 3  # SURVEY.md section 8d (fused minimum, dense grid)
-    part_bytes = 212.0 * args.particles
+    alg_bytes = 212.0 * particles + 44.0 * n_grid ** 3  # SURVEY.md section 8d (fused minimum, dense grid)
+    part_bytes = 212.0 * particles
     ach = part_bytes / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": "mpm_particle_kernel<G2P,P2G> (fused gather + stress + scatter)", "achieved": round(ach, 1),
-            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None,
+    tr = (load_traffic().get(f"mpm_{tag}_block") or {})
+    roof = {"bound": "hbm", "kernel": "mpm_block_kernel<G2P,P2G> (fused gather + stress + scatter, one launch per substep)",
+            "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4),
+            "traffic": tr.get("hbm_bytes_per_launch"), "traffic_source": "profiles/pmc_traffic.json" if tr else None,
             "avg_launch_ms": round(p_ms, 5), "grid_kernel_ms": round(g_ms, 5), "launches": int(n_launch),
             "bytes_per_launch": part_bytes, "substep_algorithmic_bytes": alg_bytes}
     oob = s.out_of_bounds
     finite = bool(torch.isfinite(s.get_field("x")).all())
-    return dict(seconds=dt, particle_steps=world * args.particles * args.mpm_substeps, roofline=roof, alg_bytes=alg_bytes,
-                oob=oob, finite=finite)
+    ps = world * particles * substeps / dt
+    return {"value": ps, "unit": "particle-steps/s", "substeps": substeps, "us_per_substep": 1e6 * dt / substeps,
+            "config": {"workload": f"{particles} particles, n_grid {n_grid}, grid_lim 2, dt 1e-4, jelly ball, tree scenario "
+                                   "(impulse + ground slab), 1 scene per GPU"},
+            "algorithmic_GBps": alg_bytes * substeps / dt / 1e9,
+            "frac_of_hbm_roofline_per_gpu": alg_bytes * substeps / dt / 1e9 / PEAK_HBM_GBPS,
+            "roofline": roof, "finite": finite, "out_of_bounds": oob,
+            "rebins": int(s._get_scalar("n_rebins")), "slow_path_particle_substeps": int(s._get_scalar("slow_path_particles"))}
 
 
 def cpu_baselines(args):
@@ -235,7 +256,9 @@ def main():
     torch.cuda.set_device(device)
 
     u = bench_unet(args, rank, world, device)
-    m = None if args.no_mpm else bench_mpm(args, rank, world, device)
+    m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k")
+    # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120): where the HBM roofline fraction is meaningful
+    m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, 300, "1m")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baselines(args)
@@ -257,16 +280,9 @@ def main():
             "roofline": u["roofline"],
         }
         if m is not None:
-            ps = m["particle_steps"] / m["seconds"]
-            line["mpm"] = {
-                "value": ps, "unit": "particle-steps/s", "substeps": args.mpm_substeps,
-                "us_per_substep": 1e6 * m["seconds"] / args.mpm_substeps,
-                "config": {"workload": f"{args.particles} particles, n_grid {args.n_grid}, grid_lim 2, dt 1e-4, jelly ball, tree scenario "
-                                       "(impulse + ground slab), 1 scene per GPU"},
-                "algorithmic_GBps": m["alg_bytes"] * args.mpm_substeps * world / m["seconds"] / 1e9 / world,
-                "frac_of_hbm_roofline_per_gpu": m["alg_bytes"] * args.mpm_substeps / m["seconds"] / 1e9 / PEAK_HBM_GBPS,
-                "roofline": m["roofline"], "finite": m["finite"], "out_of_bounds": m["oob"],
-            }
+            line["mpm"] = m
+        if m_large is not None:
+            line["mpm_1m"] = m_large
         if cpu is not None:
             line["cpu_baseline"] = cpu["unet"]
             if "mpm" in line:

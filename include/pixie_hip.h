@@ -160,6 +160,13 @@ typedef struct pixie_conv_desc {
     const void* d_w16;                            /* from pixie_conv_pack_weights_f16x2, or NULL */
     const uint32_t* d_in_amax0; const uint32_t* d_in_amax1;
     float in_bound;
+    /* f16x3 path only, optional: statistics of the OUTPUT taken in the epilogue (what the next layer's LayerNorm /
+     * GroupNorm and the next f16x3 conv's scaling need), instead of a separate pass over the tensor:
+     *   d_out_stats: pixie_conv_stats_floats(desc) floats of per-tile partial sums, finalised into the
+     *   double[2*c_out] layout of pixie_channel_sums by pixie_stats_finalize; d_out_amax: |out|max (float bits),
+     *   atomicMax'ed (caller zeroes). */
+    float* d_out_stats;
+    uint32_t* d_out_amax;
 } pixie_conv_desc;
 
 /* Repack an nn.Conv3d / nn.Conv1d weight (c_out, c_in, k,k,k) into the kernel's
@@ -172,6 +179,10 @@ int64_t pixie_conv_packed16_bytes(int c_out, int c_in, int ksize);
 int pixie_conv_pack_weights_f16x2(const float* d_w_oidhw, void* d_packed, int c_out, int c_in, int ksize, void* stream);
 /* F.conv3d / nn.Conv3d forward: exact-fp32 MFMA path (d_w), or the f16x3 split path (d_w16). */
 int pixie_conv3d_forward(const pixie_conv_desc* desc, void* stream);
+/* Epilogue statistics of the f16x3 path: buffer size in floats for desc->d_out_stats (0: layer not on that path), and
+ * the reduction of that buffer to d_sums[2*c] = (sum, sum of squares) in float64. */
+int64_t pixie_conv_stats_floats(const pixie_conv_desc* desc);
+int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* desc, double* d_sums, void* stream);
 
 /* Per-channel sum and sum of squares over the spatial extent: d_sums[2*c] (float64). */
 int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream);

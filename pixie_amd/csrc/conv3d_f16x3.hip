@@ -60,6 +60,7 @@ struct Conv16Args {
     int tiles_x, tiles_y, tiles_z, n_tiles;
     int HX, HY, HZ, HYX, CS;
     unsigned mHX, mHYX;
+    float* stats; unsigned* out_amax;   // epilogue statistics (see the epilogue), or null
     int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only
 };
 
@@ -293,12 +294,21 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
     }
 
     // ---- epilogue: unscale, + bias (+ residual); C/D layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // With A.stats the statistics the NEXT layer's LayerNorm/GroupNorm needs are taken here, while the values are in
+    // registers: per output channel the sum and sum of squares over this workgroup's voxels (lane -> 32-lane DPP
+    // reduction -> 4 waves through LDS) go to stats[tile][c_out_padded][2] with plain stores, and the tile's |x|max
+    // to *out_amax; pixie_stats_finalize adds the tiles up in fp64.  That replaces one full read of the tensor.
     const float inv = __uint_as_float(A.w16[0].x) * pow2i(-ex);
+    float* red = reinterpret_cast<float*>(smem16);   // [4 waves][MB*32 rows][2], reused after the last chunk
+    if (A.stats) __syncthreads();                    // every wave is done with the activation tile
+    float wmax = 0.0f;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cout0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int co = cout0 + row;
+            float s1 = 0.0f, s2 = 0.0f;
             if (co < A.cout) {
                 const float bv = A.bias ? A.bias[co] : 0.0f;
 #pragma unroll
@@ -308,11 +318,44 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
                         float val = acc[mb][nb][r] * inv + bv;
                         if (A.residual) val += A.residual[o];
                         A.out[o] = val;
+                        s1 += val; s2 += val * val; wmax = fmaxf(wmax, fabsf(val));
                     }
                 }
             }
+            if (A.stats) {
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+                if (l31 == 0) { red[(wave * MB * 32 + row) * 2] = s1; red[(wave * MB * 32 + row) * 2 + 1] = s2; }
+            }
         }
     }
+    if (A.stats) {
+        __syncthreads();
+        if (tid < MB * 32 * 2) {
+            const float t = red[tid] + red[MB * 64 + tid] + red[2 * MB * 64 + tid] + red[3 * MB * 64 + tid];
+            A.stats[((size_t)blockIdx.x * A.coutp + cout0) * 2 + tid] = t;
+        }
+        if (A.out_amax) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+            if (lane == 0 && wmax > 0.0f) atomicMax(A.out_amax, __float_as_uint(wmax));
+        }
+    }
+}
+
+// stats[tile][coutp][2] (fp32, from the conv epilogues) -> sums[c][2] (fp64), one workgroup per channel
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ stats, int n_tiles, int coutp, double* __restrict__ sums) {
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < n_tiles; t += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(stats + ((size_t)t * coutp + c) * 2);
+        s1 += v.x; s2 += v.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    __shared__ double r[8];
+    if ((threadIdx.x & 63) == 0) { r[2 * (threadIdx.x >> 6)] = s1; r[2 * (threadIdx.x >> 6) + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) { sums[2 * c] = r[0] + r[2] + r[4] + r[6]; sums[2 * c + 1] = r[1] + r[3] + r[5] + r[7]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -659,6 +702,38 @@ static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStr
     return 0;
 }
 
+// geometry + tile selection shared by the launcher, pixie_conv_stats_floats and pixie_stats_finalize
+static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, int& NB_out) {
+    a.ID = d->in_d; a.IH = d->in_h; a.IW = d->in_w;
+    a.ups = d->upsample;
+    a.LD = a.ID << a.ups; a.LH = a.IH << a.ups; a.LW = a.IW << a.ups;
+    const int pad = d->ksize == 3 ? 1 : 0;
+    a.OD = a.LD + 2 * pad - d->ksize + 1; a.OH = a.LH + 2 * pad - d->ksize + 1; a.OW = a.LW + 2 * pad - d->ksize + 1;
+    a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
+    const long ovol = (long)a.OD * a.OH * a.OW;
+    int MB = (a.coutp >= 64) ? 2 : 1;
+    int NB = 4;
+    auto n_wg = [&](int mb, int nb) {
+        const long tiles = (ovol + 128L * nb - 1) / (128L * nb);
+        return tiles * ((a.coutp + mb * 32 - 1) / (mb * 32));
+    };
+    while (n_wg(MB, NB) < 512 && NB > 1) NB /= 2;
+    if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
+
+    const int tile_vox = 128 * NB;
+    a.TX = pow2_le16(a.OW, 32);
+    a.TY = pow2_le16(a.OH, std::max(1, std::min(4, tile_vox / a.TX)));
+    a.TZ = std::max(1, std::min(a.OD, tile_vox / (a.TX * a.TY)));
+    a.lTX = ilog2_16(a.TX); a.lTY = ilog2_16(a.TY);
+    a.tiles_x = (a.OW + a.TX - 1) / a.TX; a.tiles_y = (a.OH + a.TY - 1) / a.TY; a.tiles_z = (a.OD + a.TZ - 1) / a.TZ;
+    a.n_tiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    a.HX = a.TX - 1 + d->ksize; a.HY = a.TY - 1 + d->ksize; a.HZ = a.TZ - 1 + d->ksize;
+    a.HYX = a.HY * a.HX; a.CS = a.HZ * a.HYX;
+    a.mHX = magic_of16(a.HX); a.mHYX = magic_of16(a.HYX);
+
+    MB_out = MB; NB_out = NB;
+}
+
 static int g_conv_dbg = 0;
 static bool g_conv_ws = getenv("PIXIE_CONV_WS") != nullptr;   // measured slower on MI355X (1.95 vs 1.54 ms): off by default
 static bool g_conv_no_pipe = getenv("PIXIE_CONV_PIPE") == nullptr;   // measured slower on MI355X (see header): off by default
@@ -683,27 +758,10 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     a.residual = d->d_residual; a.out = d->d_out;
     a.amax0 = d->d_in_amax0; a.amax1 = (d->c1 > 0) ? d->d_in_amax1 : nullptr; a.in_bound = d->in_bound;
     a.dbg = g_conv_dbg;
+    a.stats = d->d_out_stats; a.out_amax = d->d_out_amax;
 
-    const long ovol = (long)a.OD * a.OH * a.OW;
-    int MB = (a.coutp >= 64) ? 2 : 1;
-    int NB = 4;
-    auto n_wg = [&](int mb, int nb) {
-        const long tiles = (ovol + 128L * nb - 1) / (128L * nb);
-        return tiles * ((a.coutp + mb * 32 - 1) / (mb * 32));
-    };
-    while (n_wg(MB, NB) < 512 && NB > 1) NB /= 2;
-    if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
-
-    const int tile_vox = 128 * NB;
-    a.TX = pow2_le16(a.OW, 32);
-    a.TY = pow2_le16(a.OH, std::max(1, std::min(4, tile_vox / a.TX)));
-    a.TZ = std::max(1, std::min(a.OD, tile_vox / (a.TX * a.TY)));
-    a.lTX = ilog2_16(a.TX); a.lTY = ilog2_16(a.TY);
-    a.tiles_x = (a.OW + a.TX - 1) / a.TX; a.tiles_y = (a.OH + a.TY - 1) / a.TY; a.tiles_z = (a.OD + a.TZ - 1) / a.TZ;
-    a.n_tiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    a.HX = a.TX - 1 + d->ksize; a.HY = a.TY - 1 + d->ksize; a.HZ = a.TZ - 1 + d->ksize;
-    a.HYX = a.HY * a.HX; a.CS = a.HZ * a.HYX;
-    a.mHX = magic_of16(a.HX); a.mHYX = magic_of16(a.HYX);
+    int MB = 0, NB = 0;
+    conv16_tiling(d, a, MB, NB);
 
     const size_t lds = (size_t)4 * a.CS * sizeof(uint4);
     PX_REQUIRE(lds <= 160 * 1024, "f16x3 conv: tile needs %zu B of LDS", lds);
@@ -712,7 +770,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     // and enough workgroups that one per CU still fills the chip
     const bool no_pipe = g_conv_no_pipe;
     const size_t lds_pipe = 2 * (lds + 2 * sizeof(uint4));   // two buffers, each with a dummy slot per plane
-    if (!no_pipe && d->ksize == 3 && MB == 2 && NB == 4 && lds_pipe <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 512) {
+    if (!no_pipe && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && lds_pipe <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 512) {
         const bool pro = d->d_pro_a != nullptr, aff = d->d_gamma != nullptr;
         const void* kern = nullptr;
         if (pro && aff && d->act == 1) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, true, 1>);
@@ -732,7 +790,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     }
     // wave-specialised variant: the full 64 x 512 tile of a 3^3 layer, both LDS buffers fit, and at least one
     // workgroup per CU
-    if (g_conv_ws && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
+    if (g_conv_ws && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
         return launch_f16x3<3, 2, 4, true>(a, 2 * lds, grid, st);
 #define PX_CONV16_CASE(KS_, MB_, NB_) \
     if (d->ksize == KS_ && MB == MB_ && NB == NB_) return launch_f16x3<KS_, MB_, NB_>(a, lds, grid, st);
@@ -754,6 +812,26 @@ extern "C" int pixie_set_option(const char* key, int value) {
     if (std::string(key) == "conv_dbg") { g_conv_dbg = value; return 0; }
     if (std::string(key) == "conv_wave_specialised") { g_conv_ws = value != 0; return 0; }
     return set_error("pixie_set_option: unknown key '%s'", key);
+}
+
+// number of floats of the epilogue statistics buffer for this descriptor (0 if the layer does not take the f16x3 path)
+extern "C" int64_t pixie_conv_stats_floats(const pixie_conv_desc* d) {
+    if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
+    Conv16Args a{};
+    int MB = 0, NB = 0;
+    conv16_tiling(d, a, MB, NB);
+    return (int64_t)a.n_tiles * a.coutp * 2;
+}
+
+extern "C" int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* d, double* d_sums, void* stream) {
+    PX_REQUIRE(d_stats && d && d_sums, "pixie_stats_finalize: null argument");
+    // recompute the tile count exactly as conv3d_f16x3_forward does
+    Conv16Args a{};
+    int MB = 0, NB = 0;
+    conv16_tiling(d, a, MB, NB);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)d->c_out), dim3(256), 0, as_stream(stream), d_stats, a.n_tiles, a.coutp, d_sums);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int64_t pixie_conv_packed16_bytes(int c_out, int c_in, int ksize) {

@@ -85,7 +85,10 @@ class HipOps:
              stride: int = 1, upsample: bool = False, pro: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
              residual: Optional[torch.Tensor] = None, w16: Optional[torch.Tensor] = None,
-             in_amax: Optional[Sequence[torch.Tensor]] = None, in_bound: float = 0.0) -> torch.Tensor:
+             in_amax: Optional[Sequence[torch.Tensor]] = None, in_bound: float = 0.0,
+             out_amax: Optional[torch.Tensor] = None):
+        """Returns the output tensor; with `out_amax` (f16x3 path) returns (output, channel sums float64 (c_out, 2))
+        computed in the conv epilogue, and atomicMax'es |output|max into out_amax."""
         x0 = parts[0]
         x1 = parts[1] if len(parts) > 1 else None
         cin0, d, h, w = x0.shape
@@ -117,7 +120,19 @@ class HipOps:
         desc.c_out = cout
         desc.d_residual = residual.data_ptr() if residual is not None else None
         desc.d_out = out.data_ptr()
+        sums = None
+        if out_amax is not None and w16 is not None:
+            nfl = self.lib.pixie_conv_stats_floats(C.byref(desc))
+            if nfl > 0:
+                stats = torch.empty(nfl, device=self.device, dtype=torch.float32)
+                desc.d_out_stats = stats.data_ptr()
+                desc.d_out_amax = out_amax.data_ptr()
         check(self.lib.pixie_conv3d_forward(C.byref(desc), self.stream), "pixie_conv3d_forward")
+        if desc.d_out_stats:
+            sums = torch.empty((cout, 2), device=self.device, dtype=torch.float64)
+            check(self.lib.pixie_stats_finalize(_ptr(stats), C.byref(desc), _ptr(sums), self.stream), "pixie_stats_finalize")
+        if out_amax is not None:
+            return out, sums
         return out
 
     def channel_sums(self, x: torch.Tensor) -> torch.Tensor:
@@ -174,6 +189,7 @@ class UNetRunner:
         self._packed: Dict[str, Tuple[int, int, torch.Tensor]] = {}
         self._packed16: Dict[str, Tuple[int, int, torch.Tensor]] = {}
         self._bounds: Dict[str, Tuple[int, int, float, float]] = {}
+        self.fuse_stats = os.environ.get("PIXIE_FUSE_STATS", "1") != "0"   # channel statistics in the conv epilogue
 
     @property
     def _f16x3(self) -> bool:
@@ -212,17 +228,21 @@ class UNetRunner:
         wmax, bmax = self._absmax(key)
         return math.sqrt(float(count)) * wmax + bmax + 1e-30
 
+    @staticmethod
+    def _new_slot(cache: dict, device) -> torch.Tensor:
+        pool = cache.get("_slots")
+        if pool is None:
+            pool = cache["_slots"] = torch.zeros(1024, dtype=torch.int32, device=device)
+            cache["_next"] = 0
+        i = cache["_next"]
+        cache["_next"] = i + 1
+        return pool[i:i + 1]
+
     def _stats(self, cache: dict, t: torch.Tensor):
         k = id(t)
         if k not in cache:
             if hasattr(self.ops, "channel_stats"):
-                pool = cache.get("_slots")
-                if pool is None:
-                    pool = cache["_slots"] = torch.zeros(1024, dtype=torch.int32, device=t.device)
-                    cache["_next"] = 0
-                i = cache["_next"]
-                cache["_next"] = i + 1
-                slot = pool[i:i + 1]
+                slot = self._new_slot(cache, t.device)
                 cache[k] = (t, self.ops.channel_stats(t, slot), slot)  # keep t alive so id() stays unique
             else:
                 cache[k] = (t, self.ops.channel_sums(t), None)
@@ -248,6 +268,14 @@ class UNetRunner:
             kw = dict(in_amax=[self._amax(cache, t) for t in parts])
         else:
             kw = dict(in_bound=bound)
+        if self.fuse_stats:
+            # the output's channel sums and |x|max come out of the conv epilogue: no separate pass over the tensor
+            slot = self._new_slot(cache, parts[0].device)
+            out, sums = ops.conv(parts, None, self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro, affine=affine,
+                                 act=act, residual=residual, w16=self._w16(wkey), out_amax=slot, **kw)
+            if sums is not None:
+                cache[id(out)] = (out, sums, slot)
+            return out
         return ops.conv(parts, None, self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro, affine=affine,
                         act=act, residual=residual, w16=self._w16(wkey), **kw)
 

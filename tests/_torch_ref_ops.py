@@ -113,7 +113,16 @@ class TorchRefOpsF16x3(TorchRefOps):
         return self.channel_sums(x)
 
     def conv(self, parts, packed_w, bias, cout, ksize, stride=1, upsample=False, pro=None, affine=None, act=0, residual=None,
-             w16=None, in_amax=None, in_bound=0.0):
+             w16=None, in_amax=None, in_bound=0.0, out_amax=None):
+        if out_amax is not None:   # epilogue statistics of the f16x3 path
+            y = self.conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, residual, w16, in_amax, in_bound)
+            out_amax.copy_(torch.maximum(out_amax.view(torch.float32), y.abs().max().reshape(1).float()).view(torch.int32))
+            yd = y.reshape(cout, -1)
+            # per-tile fp32 partial sums, fp64 across tiles -- as the HIP epilogue + pixie_stats_finalize do
+            n = yd.shape[1]
+            pad = (-n) % 512
+            t = torch.nn.functional.pad(yd, (0, pad)).reshape(cout, -1, 512)
+            return y, torch.stack([t.sum(2).double().sum(1), (t * t).sum(2).double().sum(1)], dim=1)
         if w16 is None:
             TorchRefOpsF16x3.n_exact += 1
             return super().conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, residual)

@@ -197,6 +197,27 @@ def test_conv3d_kernel_variants_are_bit_identical(ops, variant):
         assert rel_l2(got.numpy(), ref.numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [((64,), 64, (32, 32, 32), 3), ((64, 64), 64, (16, 16, 32), 3), ((64,), 8, (16, 16, 16), 3),
+                                   ((256,), 256, (4, 4, 4), 3), ((128,), 32, (8, 16, 32), 1)])
+def test_conv3d_epilogue_statistics(ops, shape):
+    """Channel sums / sums of squares / |x|max taken in the f16x3 conv epilogue (per-tile fp32 partials + fp64
+    finalize) equal a separate pixie_channel_stats pass over the written tensor."""
+    cins, cout, dims, k = shape
+    g = torch.Generator().manual_seed(23)
+    parts = [torch.randn((c,) + dims, generator=g).to(ops.device) for c in cins]
+    cin = sum(cins)
+    w = (torch.randn((cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3)).to(ops.device)
+    b = (torch.randn(cout, generator=g) + 0.5).to(ops.device)
+    slot = torch.zeros(1, dtype=torch.int32, device=ops.device)
+    out, sums = ops.conv(parts, None, b, cout, k, w16=ops.pack_conv16(w), in_amax=_amax_slots(ops, parts), out_amax=slot)
+    assert sums is not None and tuple(sums.shape) == (cout, 2)
+    slot2 = torch.zeros(1, dtype=torch.int32, device=ops.device)
+    ref = ops.channel_stats(out, slot2)
+    assert rel_l2(sums.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    assert int(slot.item()) == int(slot2.item())   # same float bits
+    assert abs(float(slot.view(torch.float32).item()) - float(out.abs().max())) == 0.0
+
+
 def test_conv3d_residual_may_alias_output_and_is_deterministic(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn((64, 16, 16, 16), generator=g).to(ops.device)
