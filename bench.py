@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -86,7 +87,8 @@ class ConvProfiler:
             out = inner(parts, packed_w, bias, cout, ksize, **kw)
             e1.record()
             cin = sum(int(p.shape[0]) for p in parts)
-            prof.records.append(((cin, cout, ksize, kw.get("stride", 1), bool(kw.get("upsample", False)), tuple(out.shape[1:])), e0, e1))
+            o = out[0] if isinstance(out, tuple) else out   # (output, epilogue channel sums) on the fused-statistics path
+            prof.records.append(((cin, cout, ksize, kw.get("stride", 1), bool(kw.get("upsample", False)), tuple(o.shape[1:])), e0, e1))
             return out
 
         ops.conv = conv
@@ -255,13 +257,15 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    u = bench_unet(args, rank, world, device)
-    m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k")
-    # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120): where the HBM roofline fraction is meaningful
-    m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, 300, "1m")
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baselines(args)
+    # stdout carries exactly ONE line (the JSON); the solver shim's reference-style progress prints go to stderr
+    with contextlib.redirect_stdout(sys.stderr):
+        u = bench_unet(args, rank, world, device)
+        m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k")
+        # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120): where the HBM roofline fraction is meaningful
+        m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, 300, "1m")
+        cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baselines(args)
 
     if rank == 0:
         vps = u["voxels"] / u["seconds"]
