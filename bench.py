@@ -214,6 +214,41 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag):
             "rebins": int(s._get_scalar("n_rebins")), "slow_path_particle_substeps": int(s._get_scalar("slow_path_particles"))}
 
 
+def bench_field_transfer(args, device):
+    """predicted 128^3 field -> per-particle properties (K = 10) for the MPM leg's particle count."""
+    from pixie_amd.material_field import field_to_particles
+    D, n = args.grid, args.particles
+    gen = torch.Generator().manual_seed(0)
+    pred = torch.zeros((11, D, D, D))
+    pred[:3] = torch.randn((3, D, D, D), generator=gen) * 0.5
+    pred[3:] = torch.nn.functional.one_hot(torch.randint(0, 8, (D, D, D), generator=gen), 8).permute(3, 0, 1, 2).float()
+    g = (torch.arange(D) - (D - 1) / 2) / (D / 2)
+    mask = ((g[:, None, None] ** 2 + g[None, :, None] ** 2 + g[None, None, :] ** 2).sqrt() < 0.7).float()
+    d = torch.randn((n, 3), generator=gen); d = d / d.norm(dim=1, keepdim=True)
+    pos = d * (0.6 * torch.rand(n, generator=gen) ** (1 / 3))[:, None]
+    pred_d, mask_d, pos_d = pred.to(device), mask.to(device), pos.to(device)
+    field_to_particles(pred_d, mask_d, [-1, -1, -1], [1, 1, 1], pos_d)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        out = field_to_particles(pred_d, mask_d, [-1, -1, -1], [1, 1, 1], pos_d)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    res = {"ms": ms, "particles_per_s": n / (ms * 1e-3), "too_far": int(out["n_too_far"]),
+           "workload": f"{D}^3 field (18 % occupied), {n} particles, K=10 nearest voxels, mean/mode"}
+    if not args.no_cpu_baseline:
+        from oracle import field_oracle
+        ns = min(n, 20000)
+        t0 = time.perf_counter()
+        field_oracle.field_to_particles(pred.numpy(), mask.numpy(), [-1, -1, -1], [1, 1, 1], pos[:ns].numpy())
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": ns / dt, "unit": "particles/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{ns} particles, same field: numpy + sklearn KNN + per-particle Python loop (the reference's method)"}
+    return res
+
+
 def cpu_baselines(args):
     """The oracle (a port: oracle/unet_oracle.py on PyTorch CPU kernels, oracle/mpm_oracle.c scalar C)
     timed on this box's host cores on a bounded sample.  Reported next to the GPU numbers, not a target."""
@@ -263,6 +298,7 @@ def main():
         m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k")
         # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120): where the HBM roofline fraction is meaningful
         m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, 300, "1m")
+        ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baselines(args)
@@ -287,6 +323,8 @@ def main():
             line["mpm"] = m
         if m_large is not None:
             line["mpm_1m"] = m_large
+        if ft is not None:
+            line["field_to_particles"] = ft
         if cpu is not None:
             line["cpu_baseline"] = cpu["unet"]
             if "mpm" in line:

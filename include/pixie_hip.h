@@ -210,6 +210,32 @@ int pixie_channel_affine(const float* d_x, const float* d_a, const float* d_b, f
 int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial,
                               float* d_combined, int32_t* d_argmax /* may be NULL */, void* stream);
 
+/* ======================================================================================
+ * (C) Field -> particle transfer between the two halves: replaces the PLY round trip
+ *     pixie/voxel/map_pred_to_coords.py:41-75,192-252 (unscale_prediction + masked voxel point list) and
+ *     PG/material_field.py:228-300 perform_knn_smoothing (sklearn K-NN + a Python loop over every particle;
+ *     MaterialProperties.assign_from_neighbors :52-78, .get_defaults :38-50).
+ * ====================================================================================== */
+typedef struct pixie_field_desc {
+    const float* d_pred;        /* network output (3 + n_classes, D, H, W): cont channels in [-1,1] units, class scores / one-hot */
+    const uint8_t* d_mask;      /* (D, H, W) occupancy, > 0 = a material point (clip_features_mask) */
+    const float* d_axis_x; const float* d_axis_y; const float* d_axis_z;  /* voxel coordinates: float32(np.linspace(min, max, D)) per axis */
+    int32_t n_classes, d, h, w;
+    double min_spacing;         /* smallest lattice spacing of the three axes */
+    double density_min, density_max, E_min, E_max, nu_min, nu_max;  /* normalization_stats/normalization_ranges.yaml */
+} pixie_field_desc;
+/* For each of the n particles (d_pos: float[n][3] in the field's coordinate frame) the k (<= 16) nearest material points;
+ * continuous properties = mean (or inverse-distance weighted mean) of the un-scaled neighbours, material id / part label =
+ * mode (ties: first in distance order; weighted: largest vote, ties to the smallest id), d_nearest = distance to the nearest
+ * point.  Particles whose nearest point is farther than nn_distance_threshold get the defaults (mean over all material
+ * points, default_material, default_part_label).  d_scratch: 64 bytes of device memory; after the call it holds
+ * double[5] = sums of (density, E, nu, conf) over the material points and their count, then uint64 = number of too-far
+ * particles.  Asynchronous on `stream`. */
+int pixie_field_to_particles(const pixie_field_desc* field, const float* d_pos, int n, int k, double nn_distance_threshold,
+                             int weighted, int default_material, int default_part_label, float* d_density, float* d_E,
+                             float* d_nu, int32_t* d_material, int32_t* d_part_label, float* d_conf, float* d_nearest,
+                             void* d_scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

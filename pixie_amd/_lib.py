@@ -51,6 +51,16 @@ class ConvDesc(C.Structure):
                 ("d_out_stats", C.c_void_p), ("d_out_amax", C.c_void_p)]
 
 
+class FieldDesc(C.Structure):
+    """struct pixie_field_desc"""
+    _fields_ = [("d_pred", C.c_void_p), ("d_mask", C.c_void_p),
+                ("d_axis_x", C.c_void_p), ("d_axis_y", C.c_void_p), ("d_axis_z", C.c_void_p),
+                ("n_classes", C.c_int32), ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("min_spacing", C.c_double),
+                ("density_min", C.c_double), ("density_max", C.c_double), ("E_min", C.c_double), ("E_max", C.c_double),
+                ("nu_min", C.c_double), ("nu_max", C.c_double)]
+
+
 # every symbol include/pixie_hip.h declares: name -> (restype, argtypes)
 _VP, _I, _I64, _D, _S = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_char_p
 _D3 = C.POINTER(C.c_double)
@@ -90,6 +100,7 @@ SIGNATURES = {
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
     "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
     "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),
+    "pixie_field_to_particles": (_I, [C.POINTER(FieldDesc), _VP, _I, _I, _D, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

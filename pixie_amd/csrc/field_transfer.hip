@@ -1,0 +1,219 @@
+// pixie_amd/csrc/field_transfer.hip -- predicted material field -> per-particle material properties on MI355X.
+//
+// Replaces, between the two halves of the hot path, what the reference does with a PLY file,
+// sklearn and a Python loop over every particle:
+//   unscale_prediction            pixie/voxel/map_pred_to_coords.py:41-75
+//   map_pred_to_ply point list    pixie/voxel/map_pred_to_coords.py:192-252 (masked voxels at np.linspace coordinates,
+//                                 material id = argmax of the class channels, conf = their max)
+//   perform_knn_smoothing         third_party/PhysGaussian/material_field.py:228-300 (K nearest material points per particle;
+//                                 MaterialProperties.assign_from_neighbors :52-78 -- mean / mode, or inverse-distance
+//                                 weighted -- and .get_defaults :38-50 for particles whose NEAREST point is too far)
+// The material points sit on the voxel lattice, so no spatial index is built: each particle walks the lattice outwards
+// in cubic shells from its own voxel, keeping the K best (distance, voxel) pairs, and stops when the next shell cannot
+// beat the K-th.  One thread per particle; the un-scaling is applied to the K winners only.  All distances in fp64
+// (sklearn computes them in fp64 from the fp32 coordinates).  Nothing touches the host.
+#include <hip/hip_runtime.h>
+
+#include "../../include/pixie_hip.h"
+#include "common.h"
+
+namespace pixie {
+
+constexpr int kMaxK = 16;
+
+struct FieldArgs {
+    const float* pred;          // [3 + ncls][D][H][W]
+    const unsigned char* mask;  // [D][H][W], > 0 = occupied
+    const float* ax; const float* ay; const float* az;   // voxel coordinates per axis (float32(np.linspace))
+    int ncls, D, H, W;
+    double hmin;                // smallest lattice spacing
+    float dmin, dmax, emin, emax, numin, numax;  // log10 density / log10 E / nu ranges
+    const float* pos; int n;    // particles [n][3], in the field's frame
+    int k; double thr; int weighted;
+    int def_material, def_label;
+    const double* sums;         // [4] sums of density, E, nu, conf over the occupied voxels, [4] = their count
+    float* density; float* E; float* nu; float* conf; int* material; int* label; float* nearest;
+    unsigned long long* n_far;
+};
+
+__device__ __forceinline__ float unscale_log(float c, float lo, float hi) {
+    c = fminf(fmaxf(c, -1.0f), 1.0f);
+    const float l = (c + 1.0f) * (hi - lo) / 2.0f + lo;   // float32 arithmetic, as numpy does on the float32 array
+    return powf(10.0f, l);
+}
+__device__ __forceinline__ float unscale_lin(float c, float lo, float hi) {
+    c = fminf(fmaxf(c, -1.0f), 1.0f);
+    return (c + 1.0f) * (hi - lo) / 2.0f + lo;
+}
+__device__ __forceinline__ void voxel_props(const FieldArgs& A, long v, float& dens, float& e, float& nu, int& mid, float& conf) {
+    const long S = (long)A.D * A.H * A.W;
+    dens = unscale_log(A.pred[v], A.dmin, A.dmax);
+    e = unscale_log(A.pred[S + v], A.emin, A.emax);
+    nu = unscale_lin(A.pred[2 * S + v], A.numin, A.numax);
+    mid = 0;
+    conf = A.pred[3 * S + v];
+    for (int c = 1; c < A.ncls; ++c) {   // np.argmax: first maximum
+        const float p = A.pred[(3 + c) * S + v];
+        if (p > conf) { conf = p; mid = c; }
+    }
+    if (A.ncls <= 1) conf = 1.0f;
+}
+
+// numpy's float32 pairwise sum for n <= 128 (what np.mean does on a float32 array): 8 running sums, then the tail
+__device__ __forceinline__ float np_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float s = 0.0f;
+        for (int i = 0; i < n; ++i) s += a[i];
+        return s;
+    }
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// per-channel sums over the occupied voxels (for MaterialProperties.get_defaults' np.mean)
+__global__ __launch_bounds__(256) void field_defaults_kernel(FieldArgs A, double* __restrict__ sums) {
+    const long S = (long)A.D * A.H * A.W;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+        if (A.mask[v] == 0) continue;
+        float d, e, nu, cf; int mid;
+        voxel_props(A, v, d, e, nu, mid, cf);
+        s[0] += d; s[1] += e; s[2] += nu; s[3] += cf; s[4] += 1.0;
+    }
+    for (int q = 0; q < 5; ++q) {
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sums[q], s[q]);
+    }
+}
+
+__global__ __launch_bounds__(128) void field_knn_kernel(FieldArgs A) {
+    const int p = blockIdx.x * 128 + threadIdx.x;
+    if (p >= A.n) return;
+    const double px = A.pos[3 * p], py = A.pos[3 * p + 1], pz = A.pos[3 * p + 2];
+    // nearest lattice index per axis (axes are monotone np.linspace arrays)
+    auto nearest_idx = [](const float* ax, int n, double x) {
+        if (n == 1) return 0;
+        const double a0 = ax[0], h = ((double)ax[n - 1] - a0) / (n - 1);
+        int i = (int)floor((x - a0) / h + 0.5);
+        return i < 0 ? 0 : (i >= n ? n - 1 : i);
+    };
+    const int cx = nearest_idx(A.ax, A.D, px), cy = nearest_idx(A.ay, A.H, py), cz = nearest_idx(A.az, A.W, pz);
+    // how far (in lattice steps) the particle is from that voxel: 0.5 inside the lattice, more outside it
+    const double off = fmax(fmax(fabs(px - A.ax[cx]), fabs(py - A.ay[cy])), fabs(pz - A.az[cz]));
+
+    double bd[kMaxK];
+    long bi[kMaxK];
+    int cnt = 0;
+    const int K = A.k;
+    const int rmax = max(max(A.D, A.H), A.W);
+    for (int r = 0; r <= rmax; ++r) {
+        for (int ix = max(cx - r, 0); ix <= min(cx + r, A.D - 1); ++ix) {
+            const int adx = abs(ix - cx);
+            const double dx = (double)A.ax[ix] - px;
+            for (int iy = max(cy - r, 0); iy <= min(cy + r, A.H - 1); ++iy) {
+                const int ady = abs(iy - cy);
+                const double dy = (double)A.ay[iy] - py;
+                const bool face = (adx == r) || (ady == r);
+                // on a face of the shell in x or y: the whole z run; otherwise only the two z end points
+                const int z0 = max(cz - r, 0), z1 = min(cz + r, A.W - 1);
+                const int step = face ? 1 : max(2 * r, 1);
+                for (int iz = cz - r; iz <= cz + r; iz += step) {
+                    if (iz < z0 || iz > z1) continue;
+                    const long v = ((long)ix * A.H + iy) * A.W + iz;
+                    if (A.mask[v] == 0) continue;
+                    const double dz = (double)A.az[iz] - pz;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    if (cnt == K && !(d2 < bd[K - 1])) continue;
+                    int j = (cnt < K) ? cnt : K - 1;      // insertion, stable for equal distances
+                    while (j > 0 && d2 < bd[j - 1]) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+                    bd[j] = d2; bi[j] = v;
+                    if (cnt < K) ++cnt;
+                }
+            }
+        }
+        // every voxel of shell r+1 is at least (r + 1) * hmin - off away
+        const double reach = (double)(r + 1) * A.hmin - off;
+        if (cnt == K && reach > 0.0 && reach * reach >= bd[K - 1]) break;
+    }
+
+    const double nearest = cnt > 0 ? sqrt(bd[0]) : 1e300;
+    A.nearest[p] = (float)nearest;
+    if (cnt < K || nearest > A.thr) {   // MaterialProperties.get_defaults (:38-50)
+        atomicAdd(A.n_far, 1ull);
+        const double c = A.sums[4] > 0.0 ? A.sums[4] : 1.0;
+        A.density[p] = (float)(A.sums[0] / c); A.E[p] = (float)(A.sums[1] / c); A.nu[p] = (float)(A.sums[2] / c);
+        A.conf[p] = (float)(A.sums[3] / c);
+        A.material[p] = A.def_material; A.label[p] = A.def_label;
+        return;
+    }
+    float dens[kMaxK], ee[kMaxK], nn[kMaxK], cf[kMaxK];
+    int mid[kMaxK];
+    for (int j = 0; j < K; ++j) voxel_props(A, bi[j], dens[j], ee[j], nn[j], mid[j], cf[j]);
+    double w[kMaxK];
+    if (A.weighted) {
+        double ws = 0.0;
+        for (int j = 0; j < K; ++j) { w[j] = 1.0 / (sqrt(bd[j]) + 1e-8); ws += w[j]; }
+        for (int j = 0; j < K; ++j) w[j] /= ws;
+        double a = 0, b = 0, c = 0, d = 0;
+        for (int j = 0; j < K; ++j) { a += w[j] * dens[j]; b += w[j] * ee[j]; c += w[j] * nn[j]; d += w[j] * cf[j]; }
+        A.density[p] = (float)a; A.E[p] = (float)b; A.nu[p] = (float)c; A.conf[p] = (float)d;
+    } else {
+        const float fk = (float)K;
+        A.density[p] = np_sum_f32(dens, K) / fk; A.E[p] = np_sum_f32(ee, K) / fk;
+        A.nu[p] = np_sum_f32(nn, K) / fk; A.conf[p] = np_sum_f32(cf, K) / fk;
+    }
+    // mode: Counter.most_common(1) -> among the most frequent ids the one met first in distance order;
+    // weighted: np.unique + bincount(weights) + argmax -> the SMALLEST id among equal vote sums
+    int best = mid[0];
+    double best_v = -1.0;
+    for (int j = 0; j < K; ++j) {
+        bool seen = false;
+        for (int q = 0; q < j; ++q) seen = seen || (mid[q] == mid[j]);
+        if (seen) continue;
+        double votes = 0.0;
+        for (int q = j; q < K; ++q) if (mid[q] == mid[j]) votes += A.weighted ? w[q] : 1.0;
+        const bool better = A.weighted ? (votes > best_v || (votes == best_v && mid[j] < best)) : (votes > best_v);
+        if (better) { best_v = votes; best = mid[j]; }
+    }
+    A.material[p] = best; A.label[p] = best;
+}
+
+}  // namespace pixie
+
+using namespace pixie;
+
+extern "C" int pixie_field_to_particles(const pixie_field_desc* f, const float* d_pos, int n, int k, double nn_distance_threshold,
+                                        int weighted, int default_material, int default_part_label, float* d_density, float* d_E,
+                                        float* d_nu, int32_t* d_material, int32_t* d_part_label, float* d_conf, float* d_nearest,
+                                        void* d_scratch, void* stream) {
+    PX_REQUIRE(f && d_pos && d_density && d_E && d_nu && d_material && d_part_label && d_conf && d_nearest && d_scratch,
+               "pixie_field_to_particles: null argument");
+    PX_REQUIRE(f->d_pred && f->d_mask && f->d_axis_x && f->d_axis_y && f->d_axis_z, "pixie_field_to_particles: null field pointer");
+    PX_REQUIRE(n > 0 && k >= 1 && k <= kMaxK, "pixie_field_to_particles: need n > 0 and 1 <= k <= %d", kMaxK);
+    PX_REQUIRE(f->n_classes >= 1 && f->d > 0 && f->h > 0 && f->w > 0, "pixie_field_to_particles: bad field shape");
+    hipStream_t st = as_stream(stream);
+    FieldArgs A{};
+    A.pred = f->d_pred; A.mask = f->d_mask; A.ax = f->d_axis_x; A.ay = f->d_axis_y; A.az = f->d_axis_z;
+    A.ncls = f->n_classes; A.D = f->d; A.H = f->h; A.W = f->w;
+    A.hmin = f->min_spacing;
+    A.dmin = (float)f->density_min; A.dmax = (float)f->density_max; A.emin = (float)f->E_min; A.emax = (float)f->E_max;
+    A.numin = (float)f->nu_min; A.numax = (float)f->nu_max;
+    A.pos = d_pos; A.n = n; A.k = k; A.thr = nn_distance_threshold; A.weighted = weighted;
+    A.def_material = default_material; A.def_label = default_part_label;
+    double* sums = static_cast<double*>(d_scratch);               // [5] doubles, then the too-far counter
+    A.sums = sums;
+    A.n_far = reinterpret_cast<unsigned long long*>(sums + 5);
+    A.density = d_density; A.E = d_E; A.nu = d_nu; A.conf = d_conf; A.material = d_material; A.label = d_part_label; A.nearest = d_nearest;
+    PX_CHECK_HIP(hipMemsetAsync(d_scratch, 0, 6 * sizeof(double), st));
+    const long S = (long)A.D * A.H * A.W;
+    hipLaunchKernelGGL(field_defaults_kernel, dim3((unsigned)std::min<long>(1024, (S + 255) / 256)), dim3(256), 0, st, A, sums);
+    hipLaunchKernelGGL(field_knn_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, A);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
