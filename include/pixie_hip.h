@@ -167,6 +167,10 @@ typedef struct pixie_conv_desc {
      *   atomicMax'ed (caller zeroes). */
     float* d_out_stats;
     uint32_t* d_out_amax;
+    /* f16x3 path only, optional: pixie_conv_workspace_bytes(desc) bytes of device scratch.  With it, layers whose output
+     * is too small to fill the chip (the 16^3 / 32^3 levels) split their channel chunks over up to 8 workgroup slices
+     * (deterministic: partial outputs are added in a fixed order); such layers do not produce d_out_stats. */
+    void* d_workspace;
 } pixie_conv_desc;
 
 /* Repack an nn.Conv3d / nn.Conv1d weight (c_out, c_in, k,k,k) into the kernel's
@@ -182,6 +186,7 @@ int pixie_conv3d_forward(const pixie_conv_desc* desc, void* stream);
 /* Epilogue statistics of the f16x3 path: buffer size in floats for desc->d_out_stats (0: layer not on that path), and
  * the reduction of that buffer to d_sums[2*c] = (sum, sum of squares) in float64. */
 int64_t pixie_conv_stats_floats(const pixie_conv_desc* desc);
+int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* desc);
 int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* desc, double* d_sums, void* stream);
 
 /* Per-channel sum and sum of squares over the spatial extent: d_sums[2*c] (float64). */

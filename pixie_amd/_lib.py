@@ -48,7 +48,8 @@ class ConvDesc(C.Structure):
                 ("d_residual", C.c_void_p), ("d_out", C.c_void_p),
                 ("d_w16", C.c_void_p), ("d_in_amax0", C.c_void_p), ("d_in_amax1", C.c_void_p),
                 ("in_bound", C.c_float),
-                ("d_out_stats", C.c_void_p), ("d_out_amax", C.c_void_p)]
+                ("d_out_stats", C.c_void_p), ("d_out_amax", C.c_void_p),
+                ("d_workspace", C.c_void_p)]
 
 
 class FieldDesc(C.Structure):
@@ -92,6 +93,7 @@ SIGNATURES = {
     "pixie_conv_pack_weights_f16x2": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "pixie_conv3d_forward": (_I, [C.POINTER(ConvDesc), _VP]),
     "pixie_conv_stats_floats": (_I64, [C.POINTER(ConvDesc)]),
+    "pixie_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
     "pixie_stats_finalize": (_I, [_VP, C.POINTER(ConvDesc), _VP, _VP]),
     "pixie_channel_stats": (_I, [_VP, _I, _I64, _VP, _VP, _VP]),
     "pixie_tensor_amax": (_I, [_VP, _I64, _VP, _VP]),

@@ -61,6 +61,7 @@ struct Conv16Args {
     int HX, HY, HZ, HYX, CS;
     unsigned mHX, mHYX;
     float* stats; unsigned* out_amax;   // epilogue statistics (see the epilogue), or null
+    float* partial; int chunks_per_slice;   // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps) and writes partial[z]
     int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only
 };
 
@@ -285,9 +286,11 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
         }
         if (loader) return;
     } else {
-        for (int c_base = 0; c_base < A.cin; c_base += 16) {
+        const int c_begin = A.partial ? (int)blockIdx.z * A.chunks_per_slice * 16 : 0;
+        const int c_end = A.partial ? min(A.cin, c_begin + A.chunks_per_slice * 16) : A.cin;
+        for (int c_base = c_begin; c_base < c_end; c_base += 16) {
             __syncthreads();  // previous chunk fully consumed
-            if (!((A.dbg & 2) && c_base > 0)) stage_chunk(c_base, smem16, tid, NT);
+            if (!((A.dbg & 2) && c_base > c_begin)) stage_chunk(c_base, smem16, tid, NT);
             __syncthreads();
             mfma_chunk(c_base, smem16);
         }
@@ -299,6 +302,21 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
     // reduction -> 4 waves through LDS) go to stats[tile][c_out_padded][2] with plain stores, and the tile's |x|max
     // to *out_amax; pixie_stats_finalize adds the tiles up in fp64.  That replaces one full read of the tensor.
     const float inv = __uint_as_float(A.w16[0].x) * pow2i(-ex);
+    if (A.partial) {   // split-K slice: raw partial sums; bias, residual and statistics belong to splitk_reduce_kernel
+        float* dst = A.partial + (size_t)blockIdx.z * A.cout * OSP;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cout0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < A.cout) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (valid[nb]) dst[(size_t)co * OSP + ovox[nb]] = acc[mb][nb][r] * inv;
+                }
+            }
+        return;
+    }
     float* red = reinterpret_cast<float*>(smem16);   // [4 waves][MB*32 rows][2], reused after the last chunk
     if (A.stats) __syncthreads();                    // every wave is done with the activation tile
     float wmax = 0.0f;
@@ -356,6 +374,18 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
     if ((threadIdx.x & 63) == 0) { r[2 * (threadIdx.x >> 6)] = s1; r[2 * (threadIdx.x >> 6) + 1] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) { sums[2 * c] = r[0] + r[2] + r[4] + r[6]; sums[2 * c + 1] = r[1] + r[3] + r[5] + r[7]; }
+}
+
+// out = sum_s partial[s] + bias (+ residual), slices added in a fixed order (deterministic split-K)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slices, long n_elems, long osp,
+                                                            const float* __restrict__ bias, const float* residual, float* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_elems) return;
+    float v = partial[i];
+    for (int s = 1; s < slices; ++s) v += partial[(size_t)s * n_elems + i];
+    if (bias) v += bias[i / osp];
+    if (residual) v += residual[i];
+    out[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -703,7 +733,7 @@ static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStr
 }
 
 // geometry + tile selection shared by the launcher, pixie_conv_stats_floats and pixie_stats_finalize
-static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, int& NB_out) {
+static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, int& NB_out, int* slices_out = nullptr) {
     a.ID = d->in_d; a.IH = d->in_h; a.IW = d->in_w;
     a.ups = d->upsample;
     a.LD = a.ID << a.ups; a.LH = a.IH << a.ups; a.LW = a.IW << a.ups;
@@ -717,8 +747,24 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
         const long tiles = (ovol + 128L * nb - 1) / (128L * nb);
         return tiles * ((a.coutp + mb * 32 - 1) / (mb * 32));
     };
-    while (n_wg(MB, NB) < 512 && NB > 1) NB /= 2;
-    if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
+    // Split-K (needs the caller's workspace): when the output is too small to give every CU two workgroups, keep the
+    // big MFMA-efficient tile and split the channel chunks over up to 8 slices instead of shrinking the tile; the
+    // slices write partial outputs that splitk_reduce_kernel adds in a fixed order.
+    int slices = 1;
+    const int chunks = (d->c0 + d->c1) / 16;
+    const int smax = d->d_workspace ? std::min(8, chunks / 2) : 1;
+    if (smax >= 2 && n_wg(MB, NB) < 512) {
+        bool found = false;
+        for (int nb = 4; nb >= 1 && !found; nb /= 2) {
+            for (int sl = 1; sl <= smax; sl *= 2)
+                if (n_wg(MB, nb) * sl >= 512) { NB = nb; slices = sl; found = true; break; }
+        }
+        if (!found) { NB = 1; slices = 1; while (slices * 2 <= smax) slices *= 2; }
+    } else {
+        while (n_wg(MB, NB) < 512 && NB > 1) NB /= 2;
+        if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
+    }
+    if (slices_out) *slices_out = slices;
 
     const int tile_vox = 128 * NB;
     a.TX = pow2_le16(a.OW, 32);
@@ -760,12 +806,31 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     a.dbg = g_conv_dbg;
     a.stats = d->d_out_stats; a.out_amax = d->d_out_amax;
 
-    int MB = 0, NB = 0;
-    conv16_tiling(d, a, MB, NB);
+    int MB = 0, NB = 0, slices = 1;
+    conv16_tiling(d, a, MB, NB, &slices);
+    if (slices > 1) {
+        a.partial = static_cast<float*>(d->d_workspace);
+        a.chunks_per_slice = (cin / 16 + slices - 1) / slices;
+        a.stats = nullptr; a.out_amax = nullptr;   // pixie_conv_stats_floats reports 0 for these layers
+    }
 
     const size_t lds = (size_t)4 * a.CS * sizeof(uint4);
     PX_REQUIRE(lds <= 160 * 1024, "f16x3 conv: tile needs %zu B of LDS", lds);
-    const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)));
+    const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)), (unsigned)slices);
+    if (slices > 1) {
+        int rc = 1;
+#define PX_CONV16_SK(KS_, MB_, NB_) \
+        if (d->ksize == KS_ && MB == MB_ && NB == NB_) rc = launch_f16x3<KS_, MB_, NB_>(a, lds, grid, st);
+        PX_CONV16_SK(3, 2, 4) PX_CONV16_SK(3, 2, 2) PX_CONV16_SK(3, 2, 1) PX_CONV16_SK(3, 1, 4) PX_CONV16_SK(3, 1, 2) PX_CONV16_SK(3, 1, 1)
+        PX_CONV16_SK(1, 2, 4) PX_CONV16_SK(1, 2, 2) PX_CONV16_SK(1, 2, 1) PX_CONV16_SK(1, 1, 4) PX_CONV16_SK(1, 1, 2) PX_CONV16_SK(1, 1, 1)
+#undef PX_CONV16_SK
+        if (rc) return rc;
+        const long osp = (long)a.OD * a.OH * a.OW, n_elems = (long)a.cout * osp;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, a.partial, slices, n_elems, osp,
+                           a.bias, a.residual, a.out);
+        PX_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     // the software-pipelined kernel: 3^3, full 64 x 512 workgroup tile, double-buffered LDS must fit, > 1 chunk,
     // and enough workgroups that one per CU still fills the chip
     const bool no_pipe = g_conv_no_pipe;
@@ -818,9 +883,20 @@ extern "C" int pixie_set_option(const char* key, int value) {
 extern "C" int64_t pixie_conv_stats_floats(const pixie_conv_desc* d) {
     if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
     Conv16Args a{};
-    int MB = 0, NB = 0;
-    conv16_tiling(d, a, MB, NB);
-    return (int64_t)a.n_tiles * a.coutp * 2;
+    int MB = 0, NB = 0, slices = 1;
+    conv16_tiling(d, a, MB, NB, &slices);
+    return slices > 1 ? 0 : (int64_t)a.n_tiles * a.coutp * 2;
+}
+
+// bytes of d_workspace this layer can use for split-K (0: it would not split).  Decided on the shape alone.
+extern "C" int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* d) {
+    if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
+    pixie_conv_desc probe = *d;
+    probe.d_workspace = reinterpret_cast<void*>(1);   // "a workspace would be available"
+    Conv16Args a{};
+    int MB = 0, NB = 0, slices = 1;
+    conv16_tiling(&probe, a, MB, NB, &slices);
+    return slices > 1 ? (int64_t)slices * a.cout * a.OD * a.OH * a.OW * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* d, double* d_sums, void* stream) {

@@ -48,6 +48,7 @@ class HipOps:
             raise _lib.PixieHipError("pixie_amd U-Net operators run on a HIP device only (no CPU fallback)")
         self.device = device
         self.lib = _lib.load()
+        self.split_k = os.environ.get("PIXIE_CONV_SPLIT_K", "1") != "0"
 
     @property
     def stream(self):
@@ -121,6 +122,11 @@ class HipOps:
         desc.d_residual = residual.data_ptr() if residual is not None else None
         desc.d_out = out.data_ptr()
         sums = None
+        if w16 is not None and self.split_k:
+            wsb = self.lib.pixie_conv_workspace_bytes(C.byref(desc))
+            if wsb > 0:   # small-output layer: split-K scratch (torch's caching allocator makes this a pointer bump)
+                workspace = torch.empty(wsb, device=self.device, dtype=torch.uint8)
+                desc.d_workspace = workspace.data_ptr()
         if out_amax is not None and w16 is not None:
             nfl = self.lib.pixie_conv_stats_floats(C.byref(desc))
             if nfl > 0:

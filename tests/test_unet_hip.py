@@ -209,13 +209,44 @@ def test_conv3d_epilogue_statistics(ops, shape):
     w = (torch.randn((cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3)).to(ops.device)
     b = (torch.randn(cout, generator=g) + 0.5).to(ops.device)
     slot = torch.zeros(1, dtype=torch.int32, device=ops.device)
-    out, sums = ops.conv(parts, None, b, cout, k, w16=ops.pack_conv16(w), in_amax=_amax_slots(ops, parts), out_amax=slot)
+    ops.split_k = False   # split-K layers leave the statistics to a separate pass (checked in the split-K test)
+    try:
+        out, sums = ops.conv(parts, None, b, cout, k, w16=ops.pack_conv16(w), in_amax=_amax_slots(ops, parts), out_amax=slot)
+    finally:
+        ops.split_k = True
     assert sums is not None and tuple(sums.shape) == (cout, 2)
     slot2 = torch.zeros(1, dtype=torch.int32, device=ops.device)
     ref = ops.channel_stats(out, slot2)
     assert rel_l2(sums.cpu().numpy(), ref.cpu().numpy()) < 1e-6
     assert int(slot.item()) == int(slot2.item())   # same float bits
     assert abs(float(slot.view(torch.float32).item()) - float(out.abs().max())) == 0.0
+
+
+@pytest.mark.parametrize("shape", [((256,), 256, (16, 16, 16), 3), ((256, 256), 256, (16, 16, 16), 3), ((128,), 128, (32, 32, 32), 3),
+                                   ((256, 128), 256, (4, 4, 4), 3), ((256,), 256, (8, 8, 8), 1)])
+def test_conv3d_split_k(ops, shape):
+    """Small-output layers (the 16^3 / 32^3 levels) split their channel chunks over workgroup slices + a fixed-order
+    reduction: same result as the unsplit kernel to fp32 summation-order accuracy, bit-reproducible run to run, and no
+    epilogue statistics (the runner falls back to the separate pass)."""
+    cins, cout, dims, k = shape
+    g = torch.Generator().manual_seed(29)
+    parts = [torch.randn((c,) + dims, generator=g).to(ops.device) for c in cins]
+    cin = sum(cins)
+    w = (torch.randn((cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3)).to(ops.device)
+    b = torch.randn(cout, generator=g).to(ops.device)
+    res = torch.randn((cout,) + dims, generator=g).to(ops.device)
+    w16, am = ops.pack_conv16(w), _amax_slots(ops, parts)
+    slot = torch.zeros(1, dtype=torch.int32, device=ops.device)
+    a, sums = ops.conv(parts, None, b, cout, k, w16=w16, in_amax=am, residual=res, out_amax=slot)
+    a2 = ops.conv(parts, None, b, cout, k, w16=w16, in_amax=am, residual=res)
+    assert sums is None                      # this shape splits
+    assert torch.equal(a, a2)                # fixed-order reduction: deterministic
+    ops.split_k = False
+    try:
+        ref = ops.conv(parts, None, b, cout, k, w16=w16, in_amax=am, residual=res)
+    finally:
+        ops.split_k = True
+    assert rel_l2(a.cpu().numpy(), ref.cpu().numpy()) < 1e-6
 
 
 def test_conv3d_residual_may_alias_output_and_is_deterministic(ops):
