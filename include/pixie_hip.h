@@ -114,6 +114,14 @@ int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream);
  * export_particle_cov_to_torch / export_particle_R_to_torch (mpm_solver_warp.py:702-741). */
 int pixie_mpm_export_cov(pixie_mpm* h, float* d_cov /* [n][6] */, void* stream);
 int pixie_mpm_export_R(pixie_mpm* h, float* d_R /* [n][9] */, void* stream);
+/* Per-frame export for the rasteriser (PG/gs_simulation.py:591-600 with PG/utils/transformation_utils.py:19-20,108-130):
+ * positions and covariances of the first n_out particles (caller order) back in the original scene frame,
+ *   pos = ((x - shift) / scale + mean) @ M,   cov = M^T (F_trial init_cov F_trial^T / scale^2) M
+ * where shift = (1, 1, 1 + z_shift) (undoshift2center111), scale / mean come from transform2origin and
+ * M = R_k ... R_1 is the product apply_inverse_rotations walks (row-major 3x3).  d_cov may be NULL.  One launch. */
+int pixie_mpm_export_frame(pixie_mpm* h, int n_out, const double shift[3], double scale, const double mean[3],
+                           const double inv_rotation[9], float* d_pos /* [n_out][3] */, float* d_cov /* [n_out][6] or NULL */,
+                           void* stream);
 /* Particles whose 3x3x3 stencil left the grid (undefined behaviour in the reference; skipped here).
  * Synchronises `stream`. */
 int pixie_mpm_out_of_bounds(pixie_mpm* h, int64_t* count, void* stream);
@@ -209,6 +217,10 @@ int pixie_attention_forward(const float* d_qkv, float* d_out, int channels, int 
 /* y = x*a[c] + b[c] materialised (GroupNorm output feeding a non-conv consumer). */
 int pixie_channel_affine(const float* d_x, const float* d_a, const float* d_b, float* d_y, int channels,
                          int64_t spatial, void* stream);
+
+/* The voxel-grid loader of the reference's dataset item (WG/data_utils/my_data.py:160-224; features are written as
+ * (D,H,W,C) float16 by pixie/voxel/voxelize.py:86,111): .astype(float32) + permute to (C,D,H,W), on the device. */
+int pixie_voxel_grid_to_ncdhw(const void* d_feat_dhwc_f16, int d, int h, int w, int channels, float* d_out_cdhw, void* stream);
 
 /* process_batch/save_predictions (WG/trainer/inference_combined.py:124-126,186-195):
  * combined[0:3] = cont_pred; combined[3+k] = (argmax_c logits == k), ties -> lowest index. */

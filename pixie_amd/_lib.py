@@ -85,6 +85,7 @@ SIGNATURES = {
     "pixie_mpm_phase": (_I, [_VP, _I, _D, _VP]),
     "pixie_mpm_export_cov": (_I, [_VP, _VP, _VP]),
     "pixie_mpm_export_R": (_I, [_VP, _VP, _VP]),
+    "pixie_mpm_export_frame": (_I, [_VP, _I, _D3, _D, _D3, C.POINTER(C.c_double), _VP, _VP, _VP]),
     "pixie_mpm_out_of_bounds": (_I, [_VP, C.POINTER(_I64), _VP]),
     "pixie_mpm_kernel_times": (_I, [_VP, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
     "pixie_conv_cout_padded": (_I, [_I]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
     "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
     "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),
+    "pixie_voxel_grid_to_ncdhw": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "pixie_field_to_particles": (_I, [C.POINTER(FieldDesc), _VP, _I, _I, _D, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 

@@ -985,6 +985,38 @@ __global__ void cov_kernel(MpmPtrs S, const float* __restrict__ init_cov, float*
     float* o = cov + (size_t)s * 6;
     o[0] = T.m[0]; o[1] = T.m[1]; o[2] = T.m[2]; o[3] = T.m[4]; o[4] = T.m[5]; o[5] = T.m[8];
 }
+// Per-frame export for the rasteriser (PG/gs_simulation.py:591-600): positions and covariances of the first n_out
+// particles (caller order) in the original scene frame,
+//   pos_render = apply_inverse_rotations(undotransform2origin(undoshift2center111(x, z_shift), scale, mean), Rs)
+//   cov_render = apply_inverse_cov_rotations(compute_cov_from_F(F_trial, init_cov) / scale^2, Rs)
+// (PG/utils/transformation_utils.py:19-20,108-130; compute_cov_from_F mpm_utils.py:529-553) with the rotation chain
+// folded into one matrix M on the host: pos @ M, M^T cov M.
+struct FrameXform { float shift[3]; float inv_scale; float mean[3]; float inv_scale2; float M[9]; };
+__global__ void frame_export_kernel(MpmPtrs S, const float* __restrict__ init_cov, FrameXform X, int n_out, float* __restrict__ pos_out,
+                                    float* __restrict__ cov_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.n) return;
+    const int s = S.perm[i];
+    if (s >= n_out) return;
+    float q[3];
+    for (int d = 0; d < 3; ++d) q[d] = X.mean[d] + (S.x[(size_t)d * S.n + i] - X.shift[d]) * X.inv_scale;
+    for (int d = 0; d < 3; ++d) pos_out[(size_t)s * 3 + d] = q[0] * X.M[d] + q[1] * X.M[3 + d] + q[2] * X.M[6 + d];
+    if (!cov_out) return;
+    Mat3 F, C0, M;
+    for (int c = 0; c < 9; ++c) { F.m[c] = S.Ft[(size_t)c * S.n + i]; M.m[c] = X.M[c]; }
+    const float* c6 = init_cov + (size_t)s * 6;
+    C0.m[0] = c6[0]; C0.m[1] = c6[1]; C0.m[2] = c6[2];
+    C0.m[3] = c6[1]; C0.m[4] = c6[3]; C0.m[5] = c6[4];
+    C0.m[6] = c6[2]; C0.m[7] = c6[4]; C0.m[8] = c6[5];
+    Mat3 T = mat_mul_bt(mat_mul(F, C0), F);                 // F C0 F^T
+    for (int c = 0; c < 9; ++c) T.m[c] *= X.inv_scale2;
+    // M^T T M
+    Mat3 Mt;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Mt.m[3 * a + b] = M.m[3 * b + a];
+    const Mat3 Rr = mat_mul(mat_mul(Mt, T), M);
+    float* o = cov_out + (size_t)s * 6;
+    o[0] = Rr.m[0]; o[1] = Rr.m[1]; o[2] = Rr.m[2]; o[3] = Rr.m[4]; o[4] = Rr.m[5]; o[5] = Rr.m[8];
+}
 // compute_R_from_F, mpm_utils.py:556-580 (stores R^T)
 __global__ void rot_kernel(MpmPtrs S, float* __restrict__ Rout, const int* perm) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1570,6 +1602,19 @@ int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream) {
 int pixie_mpm_export_cov(pixie_mpm* h, float* d_cov, void* stream) {
     PX_REQUIRE(h && d_cov, "null argument");
     hipLaunchKernelGGL(cov_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, h->init_cov, d_cov, h->S.perm);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int pixie_mpm_export_frame(pixie_mpm* h, int n_out, const double shift[3], double scale, const double mean[3],
+                           const double inv_rotation[9], float* d_pos, float* d_cov, void* stream) {
+    PX_REQUIRE(h && shift && mean && inv_rotation && d_pos, "pixie_mpm_export_frame: null argument");
+    PX_REQUIRE(n_out > 0 && n_out <= h->S.n && scale != 0.0, "pixie_mpm_export_frame: bad n_out / scale");
+    FrameXform X{};
+    for (int d = 0; d < 3; ++d) { X.shift[d] = (float)shift[d]; X.mean[d] = (float)mean[d]; }
+    X.inv_scale = (float)(1.0 / scale); X.inv_scale2 = (float)(1.0 / (scale * scale));
+    for (int c = 0; c < 9; ++c) X.M[c] = (float)inv_rotation[c];
+    hipLaunchKernelGGL(frame_export_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, h->init_cov, X, n_out, d_pos, d_cov);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }

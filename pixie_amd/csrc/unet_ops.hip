@@ -223,9 +223,40 @@ static int launch_attention(const float* qkv, float* out, int T, hipStream_t st)
     return 0;
 }
 
+// ---------------------------------------------------------------- voxel-grid loader
+// The reference's dataset item (WG/data_utils/my_data.py:160-224): features are stored (D,H,W,C) float16
+// (pixie/voxel/voxelize.py:86,111), loaded with .astype(float32) and permuted to (C,D,H,W).  Here: one pass over the
+// grid, 64 voxels x 64 channels per workgroup through an LDS tile -- 128-byte reads along C, 256-byte writes along W.
+__global__ __launch_bounds__(256) void voxel_grid_to_ncdhw_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, long nvox, int C) {
+    __shared__ float tile[64][65];
+    const long v0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {        // r: voxel inside the tile, tx: channel
+        const long v = v0 + r;
+        const int c = c0 + tx;
+        tile[r][tx] = (v < nvox && c < C) ? (float)src[v * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {        // r: channel inside the tile, tx: voxel
+        const long v = v0 + tx;
+        const int c = c0 + r;
+        if (v < nvox && c < C) dst[(size_t)c * nvox + v] = tile[tx][r];
+    }
+}
+
 }  // namespace pixie
 
 using namespace pixie;
+
+extern "C" int pixie_voxel_grid_to_ncdhw(const void* d_feat_dhwc_f16, int d, int h, int w, int channels, float* d_out_cdhw, void* stream) {
+    PX_REQUIRE(d_feat_dhwc_f16 && d_out_cdhw && d > 0 && h > 0 && w > 0 && channels > 0, "pixie_voxel_grid_to_ncdhw: bad arguments");
+    const long nvox = (long)d * h * w;
+    hipLaunchKernelGGL(voxel_grid_to_ncdhw_kernel, dim3((unsigned)((nvox + 63) / 64), (unsigned)((channels + 63) / 64)), dim3(256), 0,
+                       as_stream(stream), static_cast<const _Float16*>(d_feat_dhwc_f16), d_out_cdhw, nvox, channels);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int pixie_channel_stats(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, void* stream) {
     PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_stats: bad arguments");

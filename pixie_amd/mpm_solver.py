@@ -387,6 +387,23 @@ class MPM_Simulator_WARP:
         check(_lib.load().pixie_mpm_export_cov(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_cov")
         return out
 
+    def export_frame_for_rendering(self, gs_num, scale_origin, original_mean_pos, rotation_matrices, z_shift_value=0.0,
+                                   with_cov=True):
+        """The per-frame hand-off to the rasteriser of gs_simulation.py:591-600 in one launch: returns
+        (pos_render (gs_num,3), cov3D_render (gs_num,6)) == (transform_to_original_coordinates(undoshift2center111(
+        export_particle_x_to_torch()[:gs_num], z_shift), scale, mean, Rs), apply_inverse_cov_rotations(
+        export_particle_cov_to_torch().view(-1,6)[:gs_num] / scale**2, Rs))."""
+        M = np.eye(3)
+        for R in reversed(list(rotation_matrices)):   # apply_inverse_rotations: p @ R_k, then @ R_{k-1}, ...
+            M = M @ np.asarray(R.detach().cpu() if torch.is_tensor(R) else R, dtype=np.float64)
+        mean = [float(v) for v in (original_mean_pos.detach().cpu() if torch.is_tensor(original_mean_pos) else original_mean_pos)]
+        pos = torch.empty((int(gs_num), 3), dtype=torch.float32, device=self.device)
+        cov = torch.empty((int(gs_num), 6), dtype=torch.float32, device=self.device) if with_cov else None
+        check(_lib.load().pixie_mpm_export_frame(self._h, int(gs_num), d3([1.0, 1.0, 1.0 + float(z_shift_value)]), float(scale_origin),
+                                                 d3(mean), (C.c_double * 9)(*M.reshape(-1)), C.c_void_p(pos.data_ptr()),
+                                                 C.c_void_p(cov.data_ptr()) if with_cov else None, self._stream), "export_frame")
+        return pos, cov
+
     def print_time_profile(self):
         """:743-746"""
         print("MPM Time profile:")

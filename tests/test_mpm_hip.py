@@ -260,3 +260,34 @@ def test_full_size_properties(hip_device):
     assert J.min() > 0.5 and J.max() < 2.0
     assert h.out_of_bounds == 0
     assert abs(h.time - 500 * sc["dt"]) < 1e-9
+
+
+def test_export_frame_for_rendering(hip_device):
+    """gs_simulation.py:591-600: positions / covariances of the first gs_num particles back in the scene frame, in one
+    launch, against a float64 restatement of transformation_utils.py:19-20,108-130 applied to the solver's own exports."""
+    sc = mpm_ball_scene(6000, seed=13, scenario="ball")
+    h = make_hip(sc)
+    h.run(sc["dt"], 25)
+    gs_num, scale, z_shift = 5000, 0.37, 0.05
+    mean = np.array([0.3, -1.2, 2.0])
+    def rot(deg, axis):
+        c, s_ = np.cos(deg / 180.0 * 3.1415926), np.sin(deg / 180.0 * 3.1415926)
+        return {0: np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]), 1: np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]),
+                2: np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])}[axis]
+    Rs = [rot(30.0, 0), rot(-75.0, 2), rot(12.0, 1)]
+    pos, cov = h.export_frame_for_rendering(gs_num, scale, torch.tensor(mean), [torch.tensor(R) for R in Rs], z_shift_value=z_shift)
+    x = get(h, "x").astype(np.float64)[:gs_num]
+    c6 = h.export_particle_cov_to_torch().cpu().numpy().reshape(-1, 6).astype(np.float64)[:gs_num]
+    p = mean + (x - np.array([1.0, 1.0, 1.0 + z_shift])) / scale          # undoshift2center111 + undotransform2origin
+    for R in reversed(Rs):                                                 # apply_inverse_rotations
+        p = p @ R
+    C = np.zeros((gs_num, 3, 3))
+    C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2] = (c6[:, k] for k in range(6))
+    C[:, 1, 0], C[:, 2, 0], C[:, 2, 1] = C[:, 0, 1], C[:, 0, 2], C[:, 1, 2]
+    C = C / scale ** 2
+    for R in reversed(Rs):                                                 # apply_inverse_cov_rotations: R^T C R
+        C = R.T @ C @ R
+    ref6 = np.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1)
+    assert pos.shape == (gs_num, 3) and cov.shape == (gs_num, 6)
+    assert rel_l2(pos.cpu().numpy(), p) < 1e-6
+    assert rel_l2(cov.cpu().numpy(), ref6) < 1e-5

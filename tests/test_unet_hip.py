@@ -387,3 +387,16 @@ def test_cpu_tensors_are_rejected(hip_device):
     m = RegressionUNet(32, 32, 32, 1, (1, 2), (), 8)
     with pytest.raises(PixieHipError):
         m(torch.zeros(1, 32, 8, 8, 8))
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 32, 64), (8, 9, 10, 3), (16, 16, 16, 768), (5, 7, 66, 130), (12, 12, 12)])
+def test_voxel_grid_loader(hip_device, shape):
+    """(D,H,W,C) float16 feature grid -> (1,C,D,H,W) float32, bit-identical to the reference's dataset item
+    (WG/data_utils/my_data.py:160-224: .astype(np.float32) + permute(3,0,1,2))."""
+    from pixie_amd.voxel_grid import load_voxel_grid
+    rng = np.random.default_rng(len(shape) + shape[-1])
+    feat = rng.normal(size=shape).astype(np.float16)
+    got = load_voxel_grid(feat, hip_device).cpu()
+    f = feat if feat.ndim == 4 else feat[..., None]
+    ref = torch.from_numpy(f.astype(np.float32)).permute(3, 0, 1, 2)[None]
+    assert got.dtype == torch.float32 and got.is_contiguous() and torch.equal(got, ref)
