@@ -101,6 +101,21 @@ struct PModSet {
     PModDev pm[kMaxPModFused];
 };
 
+// Position of tile node (lx,ly,lz) inside a STAGED tile (part[item][512]).  A tile starts one node before its block, so
+// along each axis its 8 nodes fall into three grid blocks: {0}, {1..4}, {5..7}.  The staged tile is stored sub-box by
+// sub-box (27 boxes of 1|4|3 nodes per axis, each contiguous) so that the grid kernel, whose wave owns one 4x4x4 grid
+// block, reads ONE contiguous run per covering tile instead of 16 64-byte rows scattered over 128-byte lines
+// (measured: 3x over-fetch with the plain row-major tile).
+__host__ __device__ __forceinline__ int staged_index(int lx, int ly, int lz) {
+    const int sx = (lx == 0) ? 0 : (lx <= 4 ? 1 : 2), sy = (ly == 0) ? 0 : (ly <= 4 ? 1 : 2), sz = (lz == 0) ? 0 : (lz <= 4 ? 1 : 2);
+    const int ox = (sx == 0) ? 0 : (sx == 1 ? 1 : 5), oy = (sy == 0) ? 0 : (sy == 1 ? 1 : 5), oz = (sz == 0) ? 0 : (sz == 1 ? 1 : 5);
+    const int ny = (sy == 0) ? 1 : (sy == 1 ? 4 : 3), nz = (sz == 0) ? 1 : (sz == 1 ? 4 : 3);
+    // nodes in the sub-boxes that precede (sx,sy,sz): full x-slabs, then full y-rows of this slab, then z-boxes of this row
+    const int nx = (sx == 0) ? 1 : (sx == 1 ? 4 : 3);
+    const int before = ox * 64 + nx * (oy * 8 + ny * oz);
+    return before + ((lx - ox) * ny + (ly - oy)) * nz + (lz - oz);
+}
+
 // ------------------------------------------------------------------ particle modifiers
 // apply_force (mpm_solver_warp.py:1015-1027), modify_particle_v_before_p2g (:1061-1073, :1137-1179)
 __device__ __forceinline__ void apply_pmod(const PModDev& m, int caller_idx, float time, float dt, float mass,
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
             float4* dst = S.part + (size_t)blockIdx.x * kTN;
 #pragma unroll
             for (int idx = tid; idx < kTN; idx += kWG)
-                dst[idx] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
+                dst[staged_index(idx >> 6, (idx >> 3) & 7, idx & 7)] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
                                        from_fixed(ta[3][idx], iM));
         } else {
 #pragma unroll
@@ -560,7 +575,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
                 float4 v = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
                                        from_fixed(ta[3][idx], iM));
                 if (ch > 0) { const float4 o = tf[idx]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                if (ch == nchunks - 1) S.part[(size_t)blockIdx.x * kTN + idx] = v;
+                if (ch == nchunks - 1) S.part[(size_t)blockIdx.x * kTN + staged_index(idx >> 6, (idx >> 3) & 7, idx & 7)] = v;
                 else { tf[idx] = v; ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
             }
             __syncthreads();
@@ -800,7 +815,7 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
         const int src = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
         const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
         const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;  // this node inside that block's tile
-        ptr[c] = S.part + (size_t)first * kTN + (tx * kTS + ty) * kTS + tz;
+        ptr[c] = S.part + (size_t)first * kTN + staged_index(tx, ty, tz);
         cnt[c] = n;
         maxc = max(maxc, n);
     }
