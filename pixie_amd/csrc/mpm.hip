@@ -329,16 +329,38 @@ struct ScatterIn {
     bool active;    // contributes to P2G
 };
 
+// what a particle needs from HBM before it can start: issued BEFORE the tile load + barrier so that the two latencies overlap
+struct Preload {
+    float x[3];
+    Mat3 F;          // fused kernel: F of the previous substep (G2P input); P2G-only kernel: unused
+    float mass, vol, mu, lam;
+    int material, selection;
+};
+template <bool DO_G2P, bool DO_P2G>
+__device__ __forceinline__ void preload_particle(const MpmPtrs& S, int p, Preload& L) {
+    const int n = S.n;
+    L.selection = S.selection[p];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) L.x[d] = S.x[d * n + p];
+    if (DO_G2P) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L.F.m[i] = S.F[i * n + p];
+    }
+    if (DO_P2G) {
+        L.mass = S.mass[p]; L.vol = S.vol[p]; L.mu = S.mu[p]; L.lam = S.lam[p]; L.material = S.material[p];
+    }
+}
+
 template <bool DO_G2P, bool DO_P2G>
 __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
-                                                int oz, const float4* tv, ScatterIn& out) {
+                                                int oz, const float4* tv, const Preload& L, ScatterIn& out) {
     out.active = false;
-    if (S.selection[p] != 0) return;
+    if (L.selection != 0) return;
     const int n = S.n;
     float x[3], v[3];
     Mat3 C, Ft;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) x[d] = S.x[d * n + p];
+    for (int d = 0; d < 3; ++d) x[d] = L.x[d];
 
     if (DO_G2P) {
         const Stencil st = make_stencil(x[0], x[1], x[2], S.inv_dx);
@@ -346,9 +368,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
             atomicAdd(S.oob, 1ull);
             return;
         }
-        Mat3 Fold;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Fold.m[i] = S.F[i * n + p];
+        const Mat3& Fold = L.F;
         float nv[3];
         Mat3 B, G;
         const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
@@ -402,7 +422,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
     }
 
     if (DO_P2G) {
-        const float mass = S.mass[p];
+        const float mass = L.mass;
         if (pms.n > 0) {
             const float v_before[3] = {v[0], v[1], v[2]};
             const int ci = S.perm[p];
@@ -410,8 +430,8 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
             if (!DO_G2P && (v[0] != v_before[0] || v[1] != v_before[1] || v[2] != v_before[2]))
                 for (int d = 0; d < 3; ++d) S.v[d * n + p] = v[d];
         }
-        const int material = S.material[p];
-        float mu = S.mu[p], lam = S.lam[p];
+        const int material = L.material;
+        float mu = L.mu, lam = L.lam;
         float ys = (material == 1 || material == 3 || material == 5) ? S.ys[p] : 0.0f;
         const float bulk = (material == 6) ? S.bulk[p] : 0.0f;
         const float mu0 = mu, lam0 = lam, ys0 = ys;
@@ -432,7 +452,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
                 if (sp.rpic < -0.001f) c = 0.0f;
                 out.A.m[3 * a + b] = mass * c * S.dx;  // dpos = (ijk - fx) * dx
             }
-        const float ks = -sp.dt * S.vol[p] * S.inv_dx;  // dt * (-vol * tau * dweight), dweight = dw*w*w*inv_dx
+        const float ks = -sp.dt * L.vol * S.inv_dx;  // dt * (-vol * tau * dweight), dweight = dw*w*w*inv_dx
 #pragma unroll
         for (int i = 0; i < 9; ++i) out.T.m[i] = ks * tau.m[i];
 #pragma unroll
@@ -475,6 +495,9 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
     const int ox = bx * kBS - 1, oy = by * kBS - 1, oz = bz * kBS - 1;
     const int ng = S.ng;
+    Preload L;
+    L.selection = 1;
+    if (tid < it.z) preload_particle<DO_G2P, DO_P2G>(S, it.y + tid, L);   // in flight while the tile is staged
 #pragma unroll
     for (int idx = tid; idx < kTN; idx += kWG) {
         if (DO_G2P) {
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         const int q = tid;
         ScatterIn in;
         in.active = false;
-        if (q < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + q, ox, oy, oz, tv, in);
+        if (q < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
         if (!DO_P2G) return;
 
         // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----

@@ -458,12 +458,36 @@ class RegressionUNet(_PixieUNet):
                                     tuple(attention_resolutions), grid_size, out_channels))
 
 
+_SIDE_STREAMS: Dict[str, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
+
+
+def _side_streams(device):
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _SIDE_STREAMS[key]
+
+
 @torch.no_grad()
 def predict_material_field(seg_network: SegmentationUNet, cont_network: RegressionUNet, feat_grid: torch.Tensor):
     """The compute of process_batch + save_predictions (trainer/inference_combined.py:122-126,186-195):
     returns (combined (N, 3+num_classes, D, H, W), seg_pred (N, D, H, W) int32, seg_logits, cont_pred)."""
-    seg_logits = seg_network(feat_grid)
-    cont_pred = cont_network(feat_grid)
+    if os.environ.get("PIXIE_DUAL_STREAM", "0") == "1" and feat_grid.is_cuda:
+        # the two networks are independent: run them on two HIP streams so that one network's small kernels and
+        # kernel tails fill the CUs the other leaves idle
+        cur = torch.cuda.current_stream()
+        s1, s2 = _side_streams(feat_grid.device)
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            seg_logits = seg_network(feat_grid)
+        with torch.cuda.stream(s2):
+            cont_pred = cont_network(feat_grid)
+        feat_grid.record_stream(s1); feat_grid.record_stream(s2)
+        cur.wait_stream(s1); cur.wait_stream(s2)
+        seg_logits.record_stream(cur); cont_pred.record_stream(cur)
+    else:
+        seg_logits = seg_network(feat_grid)
+        cont_pred = cont_network(feat_grid)
     ops = seg_network._runner.ops
     combined, seg_pred = [], []
     for n in range(feat_grid.shape[0]):

@@ -10,6 +10,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void scatter_kernel(const int* __restrict__ base_idx, float* __restrict__ out, int rounds) {
     __shared__ float tf[4][TN];
     __shared__ unsigned long long tq[4][TN];
+    double* td = reinterpret_cast<double*>(&tq[0][0]);
     unsigned* tu = reinterpret_cast<unsigned*>(&tf[0][0]);
     const int tid = threadIdx.x;
     for (int i = tid; i < TN; i += 256) { for (int c = 0; c < 4; ++c) { tf[c][i] = 0.f; tq[c][i] = 0ull; } }
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int* __restrict__ ba
                         if (MODE == 2) atomicAdd(&tq[c][idx], (unsigned long long)(long long)(v * 1048576.f));  // ds_add_u64
                         if (MODE == 3) tf[c][idx] += v;                                               // racy RMW (timing only)
                         if (MODE == 4) { float old = atomicAdd(&tf[c][idx], v); val += old * 1e-30f; }  // returning
+                        if (MODE == 5) atomicAdd(&td[c * TN + idx], (double)v);                          // ds_add_f64
                     }
                 }
         val += 1e-6f;
@@ -86,6 +88,7 @@ int main() {
     run_scatter<2>("ds_add_u64 random cells", d_base, d_out, blocks, rounds);
     run_scatter<3>("plain RMW (racy)", d_base, d_out, blocks, rounds);
     run_scatter<4>("ds_add_rtn_f32", d_base, d_out, blocks, rounds);
+    run_scatter<5>("ds_add_f64 random cells", d_base, d_out, blocks, rounds);
     // cell-sorted lanes: runs of 12 consecutive lanes share a cell (same 27 addresses)
     for (int i = 0; i < blocks * 256; ++i) { int cell = (i / 12) * 2654435761u % 216; h[i] = ((cell / 36) * 8 + (cell / 6) % 6) * 8 + cell % 6; }
     CK(hipMemcpy(d_base, h, sizeof(int) * blocks * 256, hipMemcpyHostToDevice));
