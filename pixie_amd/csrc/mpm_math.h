@@ -63,6 +63,21 @@ PX_HD Mat3 mat_udvt(const Mat3& U, const float d[3], const Mat3& V) {
     return r;
 }
 
+// 1-ulp reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the self-correcting polar iteration; IEEE on the host build
+PX_HD float px_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+PX_HD float px_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 PX_HD float px_rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return rsqrtf(x);
@@ -203,16 +218,16 @@ PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
         cof.m[8] = R.m[0] * R.m[4] - R.m[1] * R.m[3];
         const float d = R.m[0] * cof.m[0] + R.m[1] * cof.m[1] + R.m[2] * cof.m[2];
         if (it == 0) det = d;
-        const float inv_d = 1.0f / d;
+        const float inv_d = px_rcp(d);
         float a = 0.5f, b = 0.5f * inv_d;  // R <- a R + b cof
         if (it < 2) {
             float nr = 0.0f, nc = 0.0f;
             for (int i = 0; i < 9; ++i) { nr += R.m[i] * R.m[i]; nc += cof.m[i] * cof.m[i]; }
-            // g^2 = |R^-T|_F / |R|_F = |cof|_F / (|d| |R|_F)
-            const float g2 = sqrtf(nc / nr) * fabsf(inv_d);
-            const float g = sqrtf(g2);
+            // g^2 = |R^-T|_F / |R|_F = |cof|_F / (|d| |R|_F)   (only steers the convergence: approximate is fine)
+            const float g2 = px_sqrt(nc * px_rcp(nr)) * fabsf(inv_d);
+            const float g = px_sqrt(g2);
             a = 0.5f * g;
-            b = 0.5f * inv_d / g;
+            b = 0.5f * inv_d * px_rcp(g);
         }
         float delta = 0.0f;
         for (int i = 0; i < 9; ++i) {
