@@ -4,7 +4,7 @@
 //                            nn.GroupNorm / GroupNorm32 (:571-584; nn.py:17-19, :199) reduced to the
 //                            per-channel (a,b) that the conv kernel's prologue applies, so that no
 //                            normalised tensor is ever written to HBM;
-//  attention                 QKVAttention.forward (diffusion_network.py:224-242), streamed softmax;
+//  attention                 QKVAttention.forward (diffusion_network.py:224-242), streamed softmax on the fp32 matrix cores;
 //  combine                   argmax + one-hot + concat of inference_combined.py:124-126,186-195.
 #include <hip/hip_runtime.h>
 
@@ -103,93 +103,167 @@ __global__ void channel_affine_kernel(const float* __restrict__ x, const float* 
 }
 
 // ---------------------------------------------------------------- attention
-// qkv is [3C][T] (q rows 0..C-1, k rows C..2C-1, v rows 2C..3C-1); out[c][t] = sum_s softmax_s(q_t . k_s * C^-1/2) v[c][s].
-// Workgroup = 256 threads handles BQ = 16 queries; keys/values stream through LDS in tiles of BS = 32
-// with the running (max, sum) rescaling of a streamed softmax, so no T x T logits exist anywhere
+// qkv is [3C][T] (q rows 0..C-1, k rows C..2C-1, v rows 2C..3C-1); out[c][t] = sum_s softmax_s(q_t . k_s * C^-1/2) v[c][s]
+// (QKVAttention.forward, diffusion_network.py:224-242; one head of width C).  No T x T logits exist anywhere
 // (the reference materialises them: 64 MiB at 128^3, 4 GiB at 256^3).
+//
+// Exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32).  One workgroup = 16 queries x all keys, 8 waves; wave w owns the
+// key tiles {2(w+8j), 2(w+8j)+1} (pairs, so both halves of each 128-byte line of V are used by the same wave) and keeps
+// its own streamed-softmax state (m, l, O^T); the eight states are merged once at the end in a fixed order.
+//   S^T[key][q] = sum_c K[c][key] Q[c][q]   A = K tile straight from global (64-byte segments), B = Q from LDS
+//   O^T[c][q]  += sum_s V[c][s] P[s][q]     A = V tile straight from global (float4 = the 4 keys a lane owns),
+//                                           B = P = the S^T accumulator registers themselves (D layout == B layout)
+// so neither P nor V passes through LDS, and the rescale factor is a per-lane scalar (queries are MFMA columns in both).
+typedef float attn_f4 __attribute__((ext_vector_type(4)));
 constexpr int ATT_BQ = 16;
-constexpr int ATT_BS = 32;
+constexpr int ATT_WAVES = 8;
 template <int C>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+__global__ __launch_bounds__(ATT_WAVES * 64) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm;                      // [C][BQ]
-    float* Ks = Qs + C * ATT_BQ;         // [C][BS]
-    float* Vs = Ks + C * ATT_BS;         // [C][BS]
-    float* Ps = Vs + C * ATT_BS;         // [BQ][BS+1]
-    float* rowm = Ps + ATT_BQ * (ATT_BS + 1);   // [BQ] running max
-    float* rowl = rowm + ATT_BQ;                // [BQ] running sum
-    float* rowf = rowl + ATT_BQ;                // [BQ] rescale factor of this tile
-    const int tid = threadIdx.x;
+    constexpr int KS = C / 4;   // contraction steps of S^T
+    constexpr int MT = C / 16;  // 16-channel row tiles of O^T
+    float* Qs = sm;             // [C][16], pre-scaled; the region is reused for the merge
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
     const int t0 = blockIdx.x * ATT_BQ;
     const float* q = qkv;
     const float* k = qkv + (size_t)C * T;
     const float* v = qkv + (size_t)2 * C * T;
     const float scale2 = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, diffusion_network.py:233-236
-
-    for (int i = tid; i < C * ATT_BQ; i += 256) {
-        const int c = i / ATT_BQ, qi = i % ATT_BQ;
+    for (int i = tid; i < C * ATT_BQ; i += ATT_WAVES * 64) {
+        const int c = i >> 4, qi = i & 15;
         Qs[i] = (t0 + qi < T) ? q[(size_t)c * T + t0 + qi] * scale2 : 0.0f;
     }
-    if (tid < ATT_BQ) { rowm[tid] = -3.0e38f; rowl[tid] = 0.0f; }
-    constexpr int CPT = C / 16;  // output channels per thread
-    float acc[CPT];
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) acc[i] = 0.0f;
-    const int qi = tid & 15;
-    const int grp = tid >> 4;  // 0..15: key lane for the score phase, channel group for the PV phase
     __syncthreads();
 
-    for (int s0 = 0; s0 < T; s0 += ATT_BS) {
-        for (int i = tid; i < C * ATT_BS; i += 256) {
-            const int c = i / ATT_BS, sj = i % ATT_BS;
-            const bool ok = s0 + sj < T;
-            Ks[i] = ok ? k[(size_t)c * T + s0 + sj] : 0.0f;
-            Vs[i] = ok ? v[(size_t)c * T + s0 + sj] : 0.0f;
-        }
-        __syncthreads();
-        // scores: thread (qi, grp) -> keys grp and grp+16
-        float sc0 = 0.0f, sc1 = 0.0f;
-#pragma unroll 8
-        for (int c = 0; c < C; ++c) {
-            const float qv = Qs[c * ATT_BQ + qi];
-            sc0 += qv * Ks[c * ATT_BS + grp];
-            sc1 += qv * Ks[c * ATT_BS + grp + 16];
-        }
-        if (s0 + grp >= T) sc0 = -3.0e38f;
-        if (s0 + grp + 16 >= T) sc1 = -3.0e38f;
-        Ps[qi * (ATT_BS + 1) + grp] = sc0;
-        Ps[qi * (ATT_BS + 1) + grp + 16] = sc1;
-        __syncthreads();
-        if (tid < ATT_BQ) {  // one thread per query row: new max, rescale factor, exponentials, sum
-            float m = rowm[tid];
-            float mx = m;
-            for (int j = 0; j < ATT_BS; ++j) mx = fmaxf(mx, Ps[tid * (ATT_BS + 1) + j]);
-            const float f = __expf(m - mx);
-            float l = rowl[tid] * f;
-            for (int j = 0; j < ATT_BS; ++j) {
-                const float sv = Ps[tid * (ATT_BS + 1) + j];
-                const float e = (sv <= -1.0e38f) ? 0.0f : __expf(sv - mx);
-                Ps[tid * (ATT_BS + 1) + j] = e;
-                l += e;
+    attn_f4 O[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) O[i] = attn_f4{0.f, 0.f, 0.f, 0.f};
+    float m = -3.0e38f, l = 0.0f;
+    const int ntiles = (T + 15) >> 4;
+    const bool vec_ok = (T & 3) == 0;
+
+    // Operand registers are loaded in halves so that at most ~160 of them are live: K[0:KS/2) of the next tile during the
+    // PV products, K[KS/2:KS) and V[0:MT/2) at the start of S^T, V[MT/2:MT) at its midpoint.
+    constexpr int KH = KS / 2, MH = MT / 2;
+    float ka[KH], kb[KH];
+    attn_f4 va[MH], vb[MH];
+    auto load_k = [&](float (&dst)[KH], int tile, int kk0) {
+        int key = tile * 16 + col;
+        key = key < T ? key : T - 1;  // masked after the product
+        const float* kp = k + (size_t)(4 * kk0 + quad) * T + key;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) dst[kk] = kp[(size_t)(4 * kk) * T];
+    };
+    auto load_v = [&](attn_f4 (&dst)[MH], int tile, int mt0) {
+        const int key = tile * 16 + 4 * quad;
+        if (vec_ok && key + 3 < T) {
+            const float* vp = v + (size_t)(16 * mt0 + col) * T + key;
+#pragma unroll
+            for (int mt = 0; mt < MH; ++mt) dst[mt] = *reinterpret_cast<const attn_f4*>(vp + (size_t)(16 * mt) * T);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MH; ++mt) {
+                const float* vp = v + (size_t)(16 * (mt0 + mt) + col) * T;
+                attn_f4 r;
+                r.x = key + 0 < T ? vp[key + 0] : 0.0f;
+                r.y = key + 1 < T ? vp[key + 1] : 0.0f;
+                r.z = key + 2 < T ? vp[key + 2] : 0.0f;
+                r.w = key + 3 < T ? vp[key + 3] : 0.0f;
+                dst[mt] = r;
             }
-            rowm[tid] = mx; rowl[tid] = l; rowf[tid] = f;
         }
-        __syncthreads();
-        // PV: thread (qi, grp) owns channels grp*CPT .. grp*CPT+CPT-1 of query qi
-        const float f = rowf[qi];
+    };
+    auto tile_of = [&](int it) { return (((it >> 1) * ATT_WAVES + wave) << 1) + (it & 1); };
+    auto pv = [&](attn_f4 (&src)[MH], int mt0, const float (&p)[4], float f) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) acc[i] *= f;
-        for (int j = 0; j < ATT_BS; ++j) {
-            const float pj = Ps[qi * (ATT_BS + 1) + j];
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) acc[i] += pj * Vs[(grp * CPT + i) * ATT_BS + j];
+        for (int mt = 0; mt < MH; ++mt) {
+            attn_f4 o = O[mt0 + mt] * f;
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(src[mt].x, p[0], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(src[mt].y, p[1], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(src[mt].z, p[2], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(src[mt].w, p[3], o, 0, 0, 0);
+            O[mt0 + mt] = o;
         }
-        __syncthreads();
+    };
+
+    int it = 0;
+    int tile = tile_of(0);
+    if (tile < ntiles) load_k(ka, tile, 0);
+    while (tile < ntiles) {
+        load_k(kb, tile, KH);
+        load_v(va, tile, 0);
+        attn_f4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk)
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kk], Qs[(4 * kk + quad) * ATT_BQ + col], S, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_v(vb, tile, MH);
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk)
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[kk], Qs[(4 * (KH + kk) + quad) * ATT_BQ + col], S, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int next = tile_of(it + 1);
+        if (next < ntiles) load_k(ka, next, 0);  // lands during the softmax and the PV products
+        const int key0 = tile * 16 + 4 * quad;
+        float sv[4] = {S.x, S.y, S.z, S.w};
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (key0 + i >= T) sv[i] = -3.0e38f;
+            mx = fmaxf(mx, sv[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(m, mx);
+        const float f = __expf(m - mnew);
+        float p[4], ls = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[i] = (sv[i] <= -1.0e38f) ? 0.0f : __expf(sv[i] - mnew);
+            ls += p[i];
+        }
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        l = l * f + ls;
+        m = mnew;
+        pv(va, 0, p, f);
+        pv(vb, MH, p, f);
+        __builtin_amdgcn_sched_barrier(0);
+        ++it;
+        tile = next;
     }
-    if (t0 + qi < T) {
-        const float inv = 1.0f / rowl[qi];
+
+    // merge the eight per-wave states: M = max m_w, weights exp(m_w - M), fixed summation order over w
+    __syncthreads();  // every wave is done with Qs
+    float* wm = sm;                          // [W][16]
+    float* wl = wm + ATT_WAVES * ATT_BQ;     // [W][16]
+    float* wo = wl + ATT_WAVES * ATT_BQ;     // [W][C][16]
+    if (quad == 0) wm[wave * ATT_BQ + col] = m;
+    __syncthreads();
+    float M = -3.0e38f;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) out[(size_t)(grp * CPT + i) * T + t0 + qi] = acc[i] * inv;
+    for (int w = 0; w < ATT_WAVES; ++w) M = fmaxf(M, wm[w * ATT_BQ + col]);
+    const float fw = __expf(m - M);
+    if (quad == 0) wl[wave * ATT_BQ + col] = l * fw;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float* dst = wo + ((size_t)wave * C + 16 * mt + 4 * quad) * ATT_BQ + col;
+        dst[0 * ATT_BQ] = O[mt].x * fw;
+        dst[1 * ATT_BQ] = O[mt].y * fw;
+        dst[2 * ATT_BQ] = O[mt].z * fw;
+        dst[3 * ATT_BQ] = O[mt].w * fw;
+    }
+    __syncthreads();
+    for (int i = tid; i < C * ATT_BQ; i += ATT_WAVES * 64) {
+        const int c = i >> 4, qi = i & 15;
+        float acc = 0.0f, lt = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) {
+            acc += wo[((size_t)w * C + c) * ATT_BQ + qi];
+            lt += wl[w * ATT_BQ + qi];
+        }
+        if (t0 + qi < T) out[(size_t)c * T + t0 + qi] = acc / lt;
     }
 }
 
@@ -211,14 +285,16 @@ __global__ void combine_kernel(const float* __restrict__ logits, int ncls, const
 
 template <int C>
 static int launch_attention(const float* qkv, float* out, int T, hipStream_t st) {
-    const size_t lds = ((size_t)C * ATT_BQ + 2 * (size_t)C * ATT_BS + ATT_BQ * (ATT_BS + 1) + 3 * ATT_BQ) * sizeof(float);
+    const size_t merge = ((size_t)ATT_WAVES * C * ATT_BQ + 2 * ATT_WAVES * ATT_BQ) * sizeof(float);
+    const size_t qs = (size_t)C * ATT_BQ * sizeof(float);
+    const size_t lds = merge > qs ? merge : qs;
     auto kern = attention_kernel<C>;
     static bool attr_set = false;
     if (!attr_set) {
         PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((T + ATT_BQ - 1) / ATT_BQ), dim3(256), lds, st, qkv, out, T);
+    hipLaunchKernelGGL(kern, dim3((T + ATT_BQ - 1) / ATT_BQ), dim3(ATT_WAVES * 64), lds, st, qkv, out, T);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
