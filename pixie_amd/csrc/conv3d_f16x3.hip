@@ -41,6 +41,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kW16HeaderU4 = 4;  // 64-byte header in front of the packed planes: [0].x = bits of 1/s_w
 
+// Phase trace for timing studies (conv_dbg bit 2): per workgroup 16 x 64-bit words -- 100 MHz timestamps at start, after each
+// chunk's staging barrier, after each chunk's MFMA phase, at the end; word 15 = HW_ID | XCC_ID << 32.  Read back with
+// pixie::conv_trace_read (not part of the C ABI).
+constexpr int kTraceWGs = 8192, kTraceWords = 16;
+__device__ unsigned long long g_conv_trace[kTraceWGs * kTraceWords];
+
 struct Conv16Args {
     const float* in0; const float* in1;
     int c0, cin;
@@ -62,7 +68,9 @@ struct Conv16Args {
     unsigned mHX, mHYX;
     float* stats; unsigned* out_amax;   // epilogue statistics (see the epilogue), or null
     float* partial; int chunks_per_slice;   // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps) and writes partial[z]
-    int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only
+    int epi_lds;             // the launch reserved enough LDS for the transposing epilogue (4 x 32 x (32 NB + 4) + 256 MB floats)
+    int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only,
+                             // 4 = phase trace, 32 = one workgroup per CU, bits 8.. = start stagger in us
 };
 
 __device__ __forceinline__ int fast_div16(int n, int d, unsigned magic) {
@@ -104,6 +112,13 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
     const int kh = lane >> 5;
     const int l31 = lane & 31;
 
+    if ((A.dbg >> 8) > 0 && blockIdx.x < 512u) {   // timing experiment: the odd-slot workgroups of the first round start (dbg >> 8) us late
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | 4);
+        if (hw_id & 1u) {
+            const unsigned long long t_start = wall_clock64();
+            while (wall_clock64() - t_start < (unsigned long long)(A.dbg >> 8) * 100ull) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     // XCD-aware tile order: consecutive workgroups go to different XCDs (b % 8), so give each XCD a contiguous
     // run of tiles -- neighbouring tiles then share their halo planes in that XCD's L2.
     int t = blockIdx.x;
@@ -163,11 +178,26 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
 
     constexpr int TAPS = KS * KS * KS;
     // ---- stage the 16-channel chunk starting at c_base into `buf`: one voxel x 16 channels per item, two items per
-    // thread in flight (the channel index is uniform across the stagers, so the per-channel prologue constants and
-    // the in0/in1 selection are scalar; each thread issues its 32 + 4 loads before it touches any of them)
+    // thread in flight.  Everything uniform is kept out of the per-element code: the channel base pointers are scalar,
+    // the 32 per-channel prologue constants are fetched with ONE vector load per wave and broadcast into SGPRs with
+    // v_readlane, out-of-range voxels load element 0 (masked after the activation) so the 32 + 4 loads of an item pair
+    // issue back to back without exec-mask branches, and the (has-prologue, activation) switch selects one of six
+    // straight-line conversion bodies.  (The first version left those decisions to per-element code; the compiler
+    // turned the constants into dependent vector loads with s_waitcnt vmcnt(0) -- 16 of the 27 us a chunk took.)
     auto stage_chunk = [&](int c_base, uint4* buf, int stid, int nthr) {
         uint4* bHi = buf;
         uint4* bLo = buf + 2 * A.CS;
+        float pa[16], pb[16];
+        {
+            float pv = 0.0f;
+            if (A.pro_a) pv = (lane & 16) ? A.pro_b[c_base + (lane & 15)] : A.pro_a[c_base + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                pa[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), j));
+                pb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), 16 + j));
+            }
+        }
+        const bool has_aff = A.gamma != nullptr;
         for (int v0 = stid; v0 < A.CS; v0 += 2 * nthr) {
             float val[2][16];
             float gm[2], bt[2];
@@ -191,30 +221,43 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
                 for (int j = 0; j < 16; ++j) {
                     const int cg = c_base + j;
                     const float* src = (cg < A.c0) ? (A.in0 + (size_t)cg * ISP) : (A.in1 + (size_t)(cg - A.c0) * ISP);
-                    val[u][j] = ok[u] ? src[sidx[u]] : 0.0f;
+                    val[u][j] = src[sidx[u]];
                 }
                 gm[u] = 1.0f; bt[u] = 0.0f;
-                if (A.gamma && ok[u]) { gm[u] = A.gamma[sidx[u]]; bt[u] = A.beta[sidx[u]]; }
+                if (has_aff) { gm[u] = A.gamma[sidx[u]]; bt[u] = A.beta[sidx[u]]; }
             }
+            auto convert = [&](auto has_pro, auto act_c) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int vox = v0 + u * nthr;
-                if (vox >= A.CS) continue;
-                f16x8 vh[2], vl[2];
+                for (int u = 0; u < 2; ++u) {
+                    const int vox = v0 + u * nthr;
+                    f16x8 vh[2], vl[2];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float t = val[u][j];
-                    if (A.pro_a) t = t * A.pro_a[c_base + j] + A.pro_b[c_base + j];
-                    t = t * gm[u] + bt[u];
-                    const float sc = ok[u] ? act16(t, A.act) * sx : 0.0f;   // zero padding AFTER the activation
-                    const _Float16 h = (_Float16)sc;
-                    vh[j >> 3][j & 7] = h;
-                    vl[j >> 3][j & 7] = (_Float16)(sc - (float)h);
+                    for (int j = 0; j < 16; ++j) {
+                        float t = val[u][j];
+                        if (decltype(has_pro)::value) t = t * pa[j] + pb[j];
+                        t = t * gm[u] + bt[u];
+                        const float sc = ok[u] ? act16(t, decltype(act_c)::value) * sx : 0.0f;   // zero padding AFTER the activation
+                        const _Float16 h = (_Float16)sc;
+                        vh[j >> 3][j & 7] = h;
+                        vl[j >> 3][j & 7] = (_Float16)(sc - (float)h);
+                    }
+                    if (vox < A.CS) {
+                        bHi[vox] = __builtin_bit_cast(uint4, vh[0]);
+                        bHi[A.CS + vox] = __builtin_bit_cast(uint4, vh[1]);
+                        bLo[vox] = __builtin_bit_cast(uint4, vl[0]);
+                        bLo[A.CS + vox] = __builtin_bit_cast(uint4, vl[1]);
+                    }
                 }
-                bHi[vox] = __builtin_bit_cast(uint4, vh[0]);
-                bHi[A.CS + vox] = __builtin_bit_cast(uint4, vh[1]);
-                bLo[vox] = __builtin_bit_cast(uint4, vl[0]);
-                bLo[A.CS + vox] = __builtin_bit_cast(uint4, vl[1]);
+            };
+            using T = std::true_type; using F = std::false_type;
+            if (A.pro_a) {
+                if (A.act == 1) convert(T{}, std::integral_constant<int, 1>{});
+                else if (A.act == 2) convert(T{}, std::integral_constant<int, 2>{});
+                else convert(T{}, std::integral_constant<int, 0>{});
+            } else {
+                if (A.act == 1) convert(F{}, std::integral_constant<int, 1>{});
+                else if (A.act == 2) convert(F{}, std::integral_constant<int, 2>{});
+                else convert(F{}, std::integral_constant<int, 0>{});
             }
         }
     };
@@ -244,6 +287,10 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
                     ahn[mb] = __builtin_bit_cast(f16x8, wh[(size_t)nxt * tap_stride + mb * 32]);
                     aln[mb] = __builtin_bit_cast(f16x8, wl[(size_t)nxt * tap_stride + mb * 32]);
                 }
+                // keep the A loads of the next tap up here: left alone, the scheduler sinks them to just before their first
+                // use and every tap then waits a full L2 round trip (measured: 31 us per chunk instead of 22; fetching two
+                // taps ahead instead of one gains nothing more)
+                __builtin_amdgcn_sched_barrier(0);
                 f16x8 bh[NB], bl[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -288,11 +335,21 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
     } else {
         const int c_begin = A.partial ? (int)blockIdx.z * A.chunks_per_slice * 16 : 0;
         const int c_end = A.partial ? min(A.cin, c_begin + A.chunks_per_slice * 16) : A.cin;
+        const bool trace = (A.dbg & 4) && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < (unsigned)kTraceWGs;
+        unsigned long long* tr = g_conv_trace + (size_t)blockIdx.x * kTraceWords;
+        int ti = 0;
+        if (trace) tr[ti++] = wall_clock64();
         for (int c_base = c_begin; c_base < c_end; c_base += 16) {
             __syncthreads();  // previous chunk fully consumed
             if (!((A.dbg & 2) && c_base > c_begin)) stage_chunk(c_base, smem16, tid, NT);
             __syncthreads();
+            if (trace && ti < 13) tr[ti++] = wall_clock64();
             mfma_chunk(c_base, smem16);
+            if (trace && ti < 13) tr[ti++] = wall_clock64();
+        }
+        if (trace) {
+            tr[13] = ti;
+            tr[15] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
         }
     }
 
@@ -318,8 +375,59 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
         return;
     }
     float* red = reinterpret_cast<float*>(smem16);   // [4 waves][MB*32 rows][2], reused after the last chunk
-    if (A.stats) __syncthreads();                    // every wave is done with the activation tile
     float wmax = 0.0f;
+    // workgroup-uniform: every accumulator element of this tile is a real output
+    const bool full = A.epi_lds && cout0 + MB * 32 <= A.cout && (A.TX & 3) == 0 && (A.OW & 3) == 0 && 4 * NB * 32 <= A.TX * A.TY * A.TZ &&
+                      ox0 + A.TX <= A.OW && oy0 + A.TY <= A.OH && oz0 + A.TZ <= A.OD;
+    if (full) {
+        __syncthreads();   // every wave is done with the activation tile
+        // Interior tile (every tile of the 128^3 layers).  The accumulators go through LDS (the activation tile is dead)
+        // so that each lane ends up with 4 x-consecutive voxels of one row: 16-byte residual loads and stores, 8x fewer
+        // memory instructions, and a short rolled loop instead of 256 unrolled scalar stores.  (Written naively from the
+        // MFMA register layout, every residual load carried an s_waitcnt vmcnt(0) that also drained the preceding
+        // store: 256 serialised memory round trips, 42 us of a 229 us workgroup.)
+        constexpr int LDO = NB * 32 + 4;                                  // row stride in floats
+        float* ldsO = reinterpret_cast<float*>(smem16) + wave * (32 * LDO);   // this wave's 32 rows; no other wave touches it
+        red = reinterpret_cast<float*>(smem16) + 4 * 32 * LDO;
+        constexpr int LPR = NB * 8;          // lanes per row (4 voxels each)
+        constexpr int RPI = 32 / LPR;        // rows per half-wave per iteration
+        const int rsub = l31 / LPR, colq = 4 * (l31 % LPR), nbq = colq >> 5;
+        const int jq = (wave * NB + nbq) * 32 + (colq & 31);
+        const int xq = jq & (A.TX - 1), yq = (jq >> A.lTX) & (A.TY - 1), zq = jq >> (A.lTX + A.lTY);
+        const size_t ovq = ((size_t)(oz0 + zq) * A.OH + (oy0 + yq)) * A.OW + ox0 + xq;
+        const bool has_res = A.residual != nullptr, has_stats = A.stats != nullptr;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) ldsO[((r & 3) + 8 * (r >> 2) + 4 * kh) * LDO + nb * 32 + l31] = acc[mb][nb][r];
+#pragma unroll 4
+            for (int it = 0; it < 16 / RPI; ++it) {
+                const int rowl = (2 * it + kh) * RPI + rsub;
+                const int co = cout0 + mb * 32 + rowl;
+                const float4 a4 = *reinterpret_cast<const float4*>(ldsO + rowl * LDO + colq);
+                const float bv = A.bias ? A.bias[co] : 0.0f;
+                const size_t o = (size_t)co * OSP + ovq;
+                float4 v4;
+                v4.x = a4.x * inv + bv; v4.y = a4.y * inv + bv; v4.z = a4.z * inv + bv; v4.w = a4.w * inv + bv;
+                if (has_res) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(A.residual + o);
+                    v4.x += r4.x; v4.y += r4.y; v4.z += r4.z; v4.w += r4.w;
+                }
+                *reinterpret_cast<float4*>(A.out + o) = v4;
+                if (has_stats) {
+                    float s1 = (v4.x + v4.y) + (v4.z + v4.w);
+                    float s2 = (v4.x * v4.x + v4.y * v4.y) + (v4.z * v4.z + v4.w * v4.w);
+                    wmax = fmaxf(fmaxf(wmax, fmaxf(fabsf(v4.x), fabsf(v4.y))), fmaxf(fabsf(v4.z), fabsf(v4.w)));
+#pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+                    if ((l31 % LPR) == 0) { red[(wave * MB * 32 + mb * 32 + rowl) * 2] = s1; red[(wave * MB * 32 + mb * 32 + rowl) * 2 + 1] = s2; }
+                }
+            }
+        }
+    } else {
+    if (A.stats) __syncthreads();                    // every wave is done with the activation tile
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -347,6 +455,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
             }
         }
     }
+    }
     if (A.stats) {
         __syncthreads();
         if (tid < MB * 32 * 2) {
@@ -359,6 +468,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
             if (lane == 0 && wmax > 0.0f) atomicMax(A.out_amax, __float_as_uint(wmax));
         }
     }
+    if (!WS && (A.dbg & 4) && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < (unsigned)kTraceWGs)
+        g_conv_trace[(size_t)blockIdx.x * kTraceWords + 14] = wall_clock64();
 }
 
 // stats[tile][coutp][2] (fp32, from the conv epilogues) -> sums[c][2] (fp64), one workgroup per channel
@@ -781,6 +892,9 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
 }
 
 static int g_conv_dbg = 0;
+int conv_trace_read(unsigned long long* host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), (size_t)n_words * sizeof(unsigned long long));
+}
 static bool g_conv_ws = getenv("PIXIE_CONV_WS") != nullptr;   // measured slower on MI355X (1.95 vs 1.54 ms): off by default
 static bool g_conv_no_pipe = getenv("PIXIE_CONV_PIPE") == nullptr;   // measured slower on MI355X (see header): off by default
 void conv_set_pipe(bool on) { g_conv_no_pipe = !on; }
@@ -814,8 +928,13 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
         a.stats = nullptr; a.out_amax = nullptr;   // pixie_conv_stats_floats reports 0 for these layers
     }
 
-    const size_t lds = (size_t)4 * a.CS * sizeof(uint4);
+    size_t lds = (size_t)4 * a.CS * sizeof(uint4);
     PX_REQUIRE(lds <= 160 * 1024, "f16x3 conv: tile needs %zu B of LDS", lds);
+    {   // room for the transposing epilogue, as long as two workgroups still fit on a CU
+        const size_t epi = ((size_t)4 * 32 * (NB * 32 + 4) + (size_t)4 * MB * 32 * 2) * sizeof(float);
+        if (slices == 1 && epi <= 80 * 1024) { a.epi_lds = 1; if (lds < epi) lds = epi; }
+    }
+    if ((g_conv_dbg & 32) && lds < 100 * 1024) lds = 100 * 1024;   // timing experiment: one workgroup per CU
     const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)), (unsigned)slices);
     if (slices > 1) {
         int rc = 1;

@@ -22,14 +22,20 @@ __global__ __launch_bounds__(256, OCC) void k(const uint4* __restrict__ w, float
     for (int n = 0; n < 4; ++n) { bh[n] = __builtin_bit_cast(f16x8, lds[off + n * 32]); bl[n] = __builtin_bit_cast(f16x8, lds[off + n * 32 + 600]); }
 #pragma unroll 1
     for (int t = 0; t < taps; ++t) {
-        f16x8 bhn[4], bln[4];
+        f16x8 bhn[4], bln[4], ahn[2], aln[2];
         const int o2 = off + (t % 27) + 1;
-        if (MODE == 1) { for (int n = 0; n < 4; ++n) { bh[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32]); bl[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32 + 600]); } }
+        if (MODE >= 3) {   // the kernel's A-fragment stream: fragments of the next tap from global memory (L1/L2-hot)
+            const uint4* wn = w + (size_t)(((t + 1) % 27) * 256);
+            for (int m = 0; m < 2; ++m) { ahn[m] = __builtin_bit_cast(f16x8, wn[lane + m * 64]); aln[m] = __builtin_bit_cast(f16x8, wn[lane + 128 + m * 64]); }
+            if (MODE >= 4 && (t % 27) == 0) { __syncthreads(); __syncthreads(); }
+        }
+        if (MODE == 1 || MODE >= 3) { for (int n = 0; n < 4; ++n) { bh[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32]); bl[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32 + 600]); } }
         if (MODE == 2) { for (int n = 0; n < 4; ++n) { bhn[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32]); bln[n] = __builtin_bit_cast(f16x8, lds[o2 + n * 32 + 600]); } }
         for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
         for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
         for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
         if (MODE == 2) { for (int n = 0; n < 4; ++n) { bh[n] = bhn[n]; bl[n] = bln[n]; } }
+        if (MODE >= 3) { for (int m = 0; m < 2; ++m) { ah[m] = ahn[m]; al[m] = aln[m]; } }
     }
     float s = 0.f;
     for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int r = 0; r < 16; ++r) s += acc[m][n][r];
@@ -53,13 +59,15 @@ void run(const char* name, const uint4* w, float* out, int wgs, size_t lds_bytes
 
 int main() {
     uint4* w; float* out;
-    CK(hipMalloc(&w, 4096 * 16)); CK(hipMemset(w, 0x3c, 4096 * 16)); CK(hipMalloc(&out, 4096 * 256 * 4));
+    CK(hipMalloc(&w, 8192 * 16)); CK(hipMemset(w, 0x3c, 8192 * 16)); CK(hipMalloc(&out, 4096 * 256 * 4));
     run<0, 2>("B in registers, 2 WG/CU (78 KB LDS each)", w, out, 2048, 78 * 1024);
     run<1, 2>("B from LDS each tap, 2 WG/CU", w, out, 2048, 78 * 1024);
     run<2, 2>("B from LDS one tap ahead, 2 WG/CU", w, out, 2048, 78 * 1024);
     run<0, 1>("B in registers, 1 WG/CU (156 KB LDS)", w, out, 1024, 156 * 1024);
     run<1, 1>("B from LDS each tap, 1 WG/CU", w, out, 1024, 156 * 1024);
     run<2, 1>("B from LDS one tap ahead, 1 WG/CU", w, out, 1024, 156 * 1024);
+    run<3, 2>("B from LDS + A from global each tap, 2 WG/CU", w, out, 2048, 78 * 1024);
+    run<4, 2>("  ... + 2 barriers per 27 taps, 2 WG/CU", w, out, 2048, 78 * 1024);
     run<0, 2>("B in registers, 4 WG/CU (32 KB LDS each)", w, out, 4096, 32 * 1024);
     run<1, 2>("B from LDS each tap, 4 WG/CU (32 KB)", w, out, 4096, 32 * 1024);
     return 0;
