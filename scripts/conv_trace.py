@@ -64,3 +64,37 @@ print(f"timeline of CU key {k0} ({len(idx)} workgroups): S = stage end, M = mfma
 for i in idx[:10]:
     row = " ".join(f"{v:7.1f}" for v in us[i, :2 * nch + 1]) + f" | end {us[i, 14]:7.1f}"
     print(f"  wg {i:4d} slot {slot[i]}: {row}")
+
+# ---- interference: duration of each phase vs what the co-resident workgroup (other wave slot of the same CU) was doing
+import collections
+byslot = collections.defaultdict(list)
+for i in range(n_wg):
+    byslot[(key[i], slot[i])].append(i)
+def phases(i):
+    out = []
+    prev = us[i, 0]
+    for c in range(nch):
+        out.append(("S", prev, us[i, 1 + 2 * c])); out.append(("M", us[i, 1 + 2 * c], us[i, 2 + 2 * c])); prev = us[i, 2 + 2 * c]
+    out.append(("E", prev, us[i, 14]))
+    return out
+stats = collections.defaultdict(list)
+for (k, sl), lst in byslot.items():
+    partner = sorted((phases(j) for j in byslot.get((k, 1 - sl), [])), key=lambda p: p[0][1])
+    pint = [ph for pl in partner for ph in pl]
+    for i in lst:
+        for name, a, b in phases(i):
+            if b <= a:
+                continue
+            ov = collections.Counter()
+            for pn, pa_, pb_ in pint:
+                o = min(b, pb_) - max(a, pa_)
+                if o > 0:
+                    ov[pn] += o
+            tot = b - a
+            dom = max(("S", "M", "E", "idle"), key=lambda n: ov[n] if n != "idle" else tot - sum(ov.values()))
+            frac = (ov[dom] if dom != "idle" else tot - sum(ov.values())) / tot
+            if frac > 0.7:
+                stats[(name, dom)].append(tot)
+print("phase duration by what the co-resident workgroup was doing for > 70 % of it:")
+for (name, dom), v in sorted(stats.items()):
+    print(f"  {name} while partner {dom:4s}: n={len(v):5d}  mean {np.mean(v):6.2f} us  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f}")

@@ -8,11 +8,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+__device__ __forceinline__ unsigned rnd_half2(unsigned x) {   // two fp16 values in [-2, 2) with random mantissas
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return (x & 0x83ff83ffu) | 0x3c003c00u;
+}
 template <int MODE, int OCC>
-__global__ __launch_bounds__(256, OCC) void k(const uint4* __restrict__ w, float* __restrict__ out, int taps, int lds_units) {
+__global__ __launch_bounds__(256, OCC) void k(const uint4* __restrict__ w, float* __restrict__ out, int taps, int lds_units, int random) {
     extern __shared__ uint4 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < lds_units; i += 256) lds[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    for (int i = tid; i < lds_units; i += 256)
+        lds[i] = random ? make_uint4(rnd_half2(4 * i), rnd_half2(4 * i + 1), rnd_half2(4 * i + 2), rnd_half2(4 * i + 3))
+                        : make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
     __syncthreads();
     f32x16 acc[2][4];
     for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
@@ -43,14 +49,14 @@ __global__ __launch_bounds__(256, OCC) void k(const uint4* __restrict__ w, float
 }
 
 template <int MODE, int OCC>
-void run(const char* name, const uint4* w, float* out, int wgs, size_t lds_bytes) {
+void run(const char* name, const uint4* w, float* out, int wgs, size_t lds_bytes, int random = 0) {
     const int taps = 27 * 64;
     auto kern = k<MODE, OCC>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, w, out, taps, 1300);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, w, out, taps, 1300, random);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, w, out, taps, 1300);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, w, out, taps, 1300, random);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double flop = (double)wgs * 4 * taps * 24 * 2.0 * 32 * 32 * 16;
@@ -67,6 +73,17 @@ int main() {
     run<1, 1>("B from LDS each tap, 1 WG/CU", w, out, 1024, 156 * 1024);
     run<2, 1>("B from LDS one tap ahead, 1 WG/CU", w, out, 1024, 156 * 1024);
     run<3, 2>("B from LDS + A from global each tap, 2 WG/CU", w, out, 2048, 78 * 1024);
+    {   // the same loops on random operands (the constant patterns above toggle almost no bits in the multipliers)
+        uint4* wr; CK(hipMalloc(&wr, 8192 * 16));
+        unsigned* h = (unsigned*)malloc(8192 * 16);
+        unsigned x = 12345u;
+        for (int i = 0; i < 8192 * 4; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((x >> 3) & 0x83ff83ffu) | 0x3c003c00u; }
+        CK(hipMemcpy(wr, h, 8192 * 16, hipMemcpyHostToDevice));
+        run<0, 2>("RANDOM data: B in registers, 2 WG/CU", wr, out, 2048, 78 * 1024, 1);
+        run<3, 2>("RANDOM data: B from LDS + A from global, 2 WG/CU", wr, out, 2048, 78 * 1024, 1);
+        run<3, 1>("RANDOM data: B from LDS + A from global, 1 WG/CU", wr, out, 1024, 156 * 1024, 1);
+        run<0, 1>("RANDOM data: B in registers, 1 WG/CU", wr, out, 1024, 156 * 1024, 1);
+    }
     run<4, 2>("  ... + 2 barriers per 27 taps, 2 WG/CU", w, out, 2048, 78 * 1024);
     run<0, 2>("B in registers, 4 WG/CU (32 KB LDS each)", w, out, 4096, 32 * 1024);
     run<1, 2>("B from LDS each tap, 4 WG/CU (32 KB)", w, out, 4096, 32 * 1024);
