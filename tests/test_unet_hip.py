@@ -285,6 +285,29 @@ def test_conv3d_full_resolution_spot_check(ops, precision):
     assert worst < 1e-5, worst
 
 
+def test_conv3d_256_cube_stencil_and_cross_kernel(ops):
+    """BASELINE config 4 size: the 64->64 3^3 conv on a 256^3 grid (3.7 TFLOP, 4.3 GB per tensor).  Two independent
+    kernels (f16x3 and exact-fp32 MFMA) must agree everywhere, and random voxels -- including the far corner, where a
+    32-bit element offset would have wrapped -- must match a float64 evaluation of the stencil."""
+    D = 256
+    g = torch.Generator(device=ops.device).manual_seed(11)
+    x = torch.randn((64, D, D, D), generator=g, device=ops.device)
+    w = torch.randn((64, 64, 3, 3, 3), generator=g, device=ops.device) / np.sqrt(64 * 27)
+    b = torch.randn(64, generator=g, device=ops.device)
+    y16 = ops.conv([x], None, b, 64, 3, w16=ops.pack_conv16(w), in_amax=_amax_slots(ops, [x]))
+    y32 = ops.conv([x], ops.pack_conv(w), b, 64, 3)
+    assert rel_l2(y16.view(-1)[::997].cpu().numpy(), y32.view(-1)[::997].cpu().numpy()) < 2e-6
+    assert float((y16 - y32).abs().max() / y32.abs().max()) < 2e-5
+    pts = np.random.default_rng(1).integers(1, D - 1, size=(24, 3))
+    pts[:3] = [[D - 2, D - 2, D - 2], [1, 1, 1], [D - 2, 1, 128]]
+    wd, bd = w.double().cpu(), b.double().cpu()
+    for z, y, xx in pts:
+        patch = x[:, z - 1:z + 2, y - 1:y + 2, xx - 1:xx + 2].double().cpu()
+        want = (wd * patch[None]).sum(dim=(1, 2, 3, 4)) + bd
+        got = y16[:, z, y, xx].double().cpu()
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(64, 32, 32, 32), (128, 4, 4, 4), (32, 5, 7, 9), (8, 128, 128, 64)])
 def test_channel_sums_and_norm_finalize(ops, shape):
     g = torch.Generator().manual_seed(1)
