@@ -316,9 +316,9 @@ __device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int
 // The scatter accumulates in LDS with 64-bit INTEGER atomics: ds_add_f32 retires ~1 lane per 3 cycles on gfx950
 // (193 cycles per wave-instruction, measured: scripts/microbench/lds_atomics.hip), ds_add_u64 is 11x faster.  Each
 // workgroup therefore (1) computes every particle's scatter inputs, (2) takes the workgroup maximum of a bound on
-// their contributions, (3) scales by the power of two that puts that bound at 2^50 and adds round-to-nearest
-// integers (|sum of 256| < 2^58).  The LSB is 2^-50 of the largest contribution in the tile, i.e. the tile sums are
-// exact to ~1e-15 -- tighter than any fp32 summation order -- and since integer adds commute they are bit-reproducible.
+// their contributions, (3) scales by the power of two that puts that bound just below 2^42 and adds round-to-nearest
+// integers (|sum of 256| < 2^50; see to_fixed).  The LSB is 2^-42 of the largest contribution in the tile, i.e. the tile
+// sums are exact to ~2e-13 -- tighter than any fp32 summation order -- and since integer adds commute they are bit-reproducible.
 // (A 32-bit variant -- LSB 2^-21 -- was measured first: low-mass free-surface nodes lost up to 10 % of their velocity.)
 struct ScatterIn {
     float x[3];     // position after the G2P update (where the P2G stencil is taken)
@@ -462,23 +462,28 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
     }
 }
 
-constexpr double kMagicD = 6755399441055744.0;            // 1.5 * 2^52: x + kMagicD has ulp 1 for |x| < 2^51
-constexpr long long kMagicBitsD = 0x4338000000000000ll;
+// 64-bit fixed point through the double-precision adder: the mantissa field of (x + 1.5 * 2^52) is 2^51 + round(x) for
+// |x| < 2^51, so ds_add_u64 of the raw bit patterns accumulates sum(round(x_i)) modulo 2^51 in the low 51 bits whatever
+// happens above them (the N copies of the exponent and of the 2^51 offset only carry upwards).  With every contribution
+// scaled below 2^42 and at most 256 of them per node the sum stays below 2^50 and is recovered by sign-extending bit 50:
+// two instructions per contribution (v_cvt_f64_f32, v_add_f64), exact integer accumulation, order-independent.
+constexpr double kMagicD = 6755399441055744.0;            // 1.5 * 2^52
 
-// power of two s with bound * s in [2^49, 2^50)  (1 when the bound is zero / not finite)
+// power of two s with bound * s in [2^41, 2^42)  (1 when the bound is zero / not finite)
 __device__ __forceinline__ float scale_for(float bound) {
     const unsigned bits = __float_as_uint(bound);
     const int eb = (int)((bits >> 23) & 0xffu) - 127;
     if (!(bound > 0.0f) || eb > 120) return 1.0f;
-    int e = 49 - eb;
+    int e = 41 - eb;
     e = e > 120 ? 120 : (e < -80 ? -80 : e);
     return __uint_as_float((unsigned)(e + 127) << 23);
 }
 __device__ __forceinline__ unsigned long long to_fixed(float scaled) {
-    return (unsigned long long)(__double_as_longlong((double)scaled + kMagicD) - kMagicBitsD);
+    return (unsigned long long)__double_as_longlong((double)scaled + kMagicD);
 }
 __device__ __forceinline__ float from_fixed(unsigned long long v, float inv_scale) {
-    return (float)((double)(long long)v * (double)inv_scale);
+    const long long x = (long long)(v << 13) >> 13;      // low 51 bits, sign-extended
+    return (float)((double)x * (double)inv_scale);
 }
 
 #ifndef PX_MPM_WAVES
