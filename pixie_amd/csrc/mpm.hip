@@ -75,6 +75,7 @@ struct StepParams {
     float damping;
     int do_damping;
     float rpic;
+    int trace;      // timing studies: workgroups stamp s_memrealtime around their phases into g_mpm_trace
     MaterialScalars ms;
 };
 
@@ -486,6 +487,12 @@ __device__ __forceinline__ float from_fixed(unsigned long long v, float inv_scal
     return (float)((double)x * (double)inv_scale);
 }
 
+// Phase trace (pixie_mpm_set_scalar "trace" 1; read back with pixie::mpm_trace_read, not part of the C ABI): per work item 8
+// 100 MHz timestamps -- start, tile staged, particles updated (G2P + stress), scales known, scatter done, tile published.
+constexpr int kMpmTraceItems = 32768;
+__device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
+#define PX_MPM_STAMP(i) do { if (DO_G2P && DO_P2G && sp.trace && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+
 #ifndef PX_MPM_WAVES
 #define PX_MPM_WAVES 3
 #endif
@@ -500,6 +507,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
     const int ox = bx * kBS - 1, oy = by * kBS - 1, oz = bz * kBS - 1;
     const int ng = S.ng;
+    PX_MPM_STAMP(0);
     Preload L;
     L.selection = 1;
     if (tid < it.z) preload_particle<DO_G2P, DO_P2G>(S, it.y + tid, L);   // in flight while the tile is staged
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         if (DO_P2G) { ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
     }
     __syncthreads();
+    PX_MPM_STAMP(1);
 
     // One chunk of <= 256 particles per work item.  (Looping a workgroup over several chunks that share one tile --
     // folding each chunk's integer sums into an fp32 tile tf -- halves the staged-tile traffic of large scenes, but
@@ -528,6 +537,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         in.active = false;
         if (q < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
         if (!DO_P2G) return;
+        PX_MPM_STAMP(2);
 
         // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----
         Stencil st;
@@ -574,6 +584,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         bp = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
         bm = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
         const float sP = scale_for(bp), sM = scale_for(bm);
+        PX_MPM_STAMP(3);
 
         if (in.active) {
 #pragma unroll
@@ -589,6 +600,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
             });
         }
         __syncthreads();
+        PX_MPM_STAMP(4);
         const float iP = 1.0f / sP, iM = 1.0f / sM;
         if (nchunks == 1) {
             // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
@@ -608,6 +620,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
             }
             __syncthreads();
         }
+        PX_MPM_STAMP(5);
     }
 }
 
@@ -1092,6 +1105,9 @@ __global__ void grid_export_kernel(const float4* __restrict__ g, float* __restri
     else { out[3 * i] = q.x; out[3 * i + 1] = q.y; out[3 * i + 2] = q.z; }
 }
 
+int mpm_trace_read(unsigned long long* host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mpm_trace), (size_t)n_words * sizeof(unsigned long long));
+}
 }  // namespace pixie
 
 // ====================================================================== host side
@@ -1122,6 +1138,7 @@ struct pixie_mpm {
     bool needs_sort = true;                  // positions changed behind the binning's back (or never binned)
     int resort_interval = 4, steps_since_sort = 0;  // starts cautious, doubles while the measured drift allows
     bool xref_valid = false;
+    int trace = 0;
     bool resort_auto = true;                 // adapt resort_interval to the observed drift (off once the caller sets it)
     unsigned long long slow_at_rebin = 0;
     int2* blk_items = nullptr;               // per block: (first work item, item count)
@@ -1231,6 +1248,7 @@ StepParams make_params(const pixie_mpm* h, double dt, double time) {
     sp.damping = h->damping;
     sp.do_damping = (h->damping < 1.0f) ? 1 : 0;  // gate mpm_solver_warp.py:595
     sp.rpic = h->rpic;
+    sp.trace = h->trace;
     sp.ms = h->ms;
     return sp;
 }
@@ -1521,6 +1539,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
+    else if (k == "trace") h->trace = (int)value;
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
     return 0;
