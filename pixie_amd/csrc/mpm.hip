@@ -43,7 +43,7 @@ namespace pixie {
 constexpr int kBS = 4;                    // cells per block edge (particles are binned by the block of their stencil base)
 constexpr int kTS = 8;                    // tile nodes per edge: kBS + 2 (stencil reach) + 2 (one-cell drift margin each side)
 constexpr int kTN = kTS * kTS * kTS;      // 512 nodes
-constexpr int kWG = 256;                  // particles per work item / threads per workgroup
+constexpr int kWG = 256;                  // particles per work item / threads per workgroup (upper value)
 
 // rows of the particle word array
 enum Row {
@@ -504,6 +504,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
     __shared__ float4 tf[kTN];    // running fp32 tile of a multi-chunk work item
     const int4 it = S.items[blockIdx.x];
     const int tid = threadIdx.x;
+    const int nthr = blockDim.x;   // = the work-item capacity of the current binning (256; 128 on request)
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
     const int ox = bx * kBS - 1, oy = by * kBS - 1, oz = bz * kBS - 1;
     const int ng = S.ng;
@@ -511,8 +512,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
     Preload L;
     L.selection = 1;
     if (tid < it.z) preload_particle<DO_G2P, DO_P2G>(S, it.y + tid, L);   // in flight while the tile is staged
-#pragma unroll
-    for (int idx = tid; idx < kTN; idx += kWG) {
+    for (int idx = tid; idx < kTN; idx += nthr) {
         if (DO_G2P) {
             const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -581,8 +581,8 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         }
         if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
         __syncthreads();
-        bp = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
-        bm = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+        bp = fmaxf(s_red[0][0], s_red[0][1]); bm = fmaxf(s_red[1][0], s_red[1][1]);
+        if (nthr > 128) { bp = fmaxf(bp, fmaxf(s_red[0][2], s_red[0][3])); bm = fmaxf(bm, fmaxf(s_red[1][2], s_red[1][3])); }
         const float sP = scale_for(bp), sM = scale_for(bm);
         PX_MPM_STAMP(3);
 
@@ -605,13 +605,11 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         if (nchunks == 1) {
             // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
             float4* dst = S.part + (size_t)blockIdx.x * kTN;
-#pragma unroll
-            for (int idx = tid; idx < kTN; idx += kWG)
+            for (int idx = tid; idx < kTN; idx += nthr)
                 dst[staged_index(idx >> 6, (idx >> 3) & 7, idx & 7)] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
                                        from_fixed(ta[3][idx], iM));
         } else {
-#pragma unroll
-            for (int idx = tid; idx < kTN; idx += kWG) {
+            for (int idx = tid; idx < kTN; idx += nthr) {
                 float4 v = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
                                        from_fixed(ta[3][idx], iM));
                 if (ch > 0) { const float4 o = tf[idx]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
@@ -1142,7 +1140,8 @@ struct pixie_mpm {
     bool resort_auto = true;                 // adapt resort_interval to the observed drift (off once the caller sets it)
     unsigned long long slow_at_rebin = 0;
     int2* blk_items = nullptr;               // per block: (first work item, item count)
-    int item_cap = kWG;                      // particles per work item: 256 (small problems) or 1024
+    int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
+    int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
     bool pmods_were_active = false;
     float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
     bool pending_p2g = false;                // staged tiles not yet consumed by the grid kernel
@@ -1190,7 +1189,10 @@ void bind_rows(pixie_mpm* h) {
 int rebin(pixie_mpm* h, hipStream_t st) {
     MpmPtrs& S = h->S;
     const int n = S.n;
-    h->item_cap = kWG;
+    // Work-item capacity: 256 particles (one per thread).  128-thread items were measured too (set_scalar "item_cap"):
+    // 100 k particles 21.0 -> 23.8 us per launch (916 items instead of 526: the per-item tile staging / barriers /
+    // publish dominate), 1 M particles 100 -> 95 us but the grid kernel pays for twice the tiles (14.8 -> 20.7 us).
+    h->item_cap = h->item_cap_user > 0 ? h->item_cap_user : kWG;
     PX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->nblocks * sizeof(int), st));
     PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 2, 0, sizeof(int), st));
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts,
@@ -1311,18 +1313,18 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        hipLaunchKernelGGL((mpm_block_kernel<true, true>), grid, dim3(kWG), 0, st, h->S, sp, pms);
+        hipLaunchKernelGGL((mpm_block_kernel<true, true>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
     } else {
         if (g2p) {
             PModSet none{};
-            hipLaunchKernelGGL((mpm_block_kernel<true, false>), grid, dim3(kWG), 0, st, h->S, sp, none);
+            hipLaunchKernelGGL((mpm_block_kernel<true, false>), grid, dim3(h->item_cap), 0, st, h->S, sp, none);
         }
         if (p2g) {
             if (!fused_mods) {
                 for (const PModDev& m : ordered)
                     hipLaunchKernelGGL(pmod_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, m);
             }
-            hipLaunchKernelGGL((mpm_block_kernel<false, true>), grid, dim3(kWG), 0, st, h->S, sp, pms);
+            hipLaunchKernelGGL((mpm_block_kernel<false, true>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
         }
     }
     if (e0) {
@@ -1404,7 +1406,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     int rc = 0;
     S.nbk = (n_grid + kBS - 1) / kBS;
     h->nblocks = S.nbk * S.nbk * S.nbk;
-    const size_t max_items = (n + kWG - 1) / kWG + std::min<size_t>((size_t)h->nblocks, n);
+    const size_t max_items = (n + kWG / 2 - 1) / (kWG / 2) + std::min<size_t>((size_t)h->nblocks, n);   // for the smaller capacity
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
     rc |= dev_alloc(h, &S.gin, G); rc |= dev_alloc(h, &S.gout, G);
     rc |= dev_alloc(h, &S.oob, 3);
@@ -1540,6 +1542,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
     else if (k == "trace") h->trace = (int)value;
+    else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 128 || value == 256, "item_cap must be 0 (auto), 128 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
     return 0;

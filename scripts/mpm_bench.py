@@ -23,6 +23,8 @@ def main():
     apply_scene(s, sc)
     if resort > 0:
         s._set_scalar("resort_interval", resort)
+    if os.environ.get("PIXIE_MPM_ITEM_CAP"):
+        s._set_scalar("item_cap", int(os.environ["PIXIE_MPM_ITEM_CAP"]))
     s.run(sc["dt"], 64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
