@@ -88,3 +88,104 @@ def apply_material_field_to_solver(mpm_solver, pred: torch.Tensor, mask: torch.T
     mpm_solver.set_per_particle(E=res["E"], nu=res["nu"], density=res["density"], material=res["material_id"])
     mpm_solver.finalize_mu_lam()
     return res["conf"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Boundary conditions derived from the transferred field (third_party/PhysGaussian/material_field.py:364-550).
+# Both run once per scene on a few numbers, so they stay host-side like the reference's; the density clustering is
+# restated without sklearn as a radius graph over the stationary particles.
+def dbscan_labels(points: np.ndarray, eps: float, min_samples: int) -> np.ndarray:
+    """Labels as sklearn.cluster.DBSCAN(eps, min_samples).fit_predict assigns them (the reference's call,
+    material_field.py:405-406): a point is a core point when its closed eps-ball holds >= min_samples points; clusters are
+    the connected components of the core points and are numbered in the order of their lowest-index core point; a border
+    point joins the earliest-numbered cluster that has a core point within eps; everything else is noise (-1)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import cKDTree
+
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = len(pts)
+    labels = np.full(n, -1, dtype=np.int64)
+    if n == 0:
+        return labels
+    pairs = cKDTree(pts).query_pairs(float(eps), output_type="ndarray")           # i < j, |pi - pj| <= eps
+    degree = np.bincount(pairs.ravel(), minlength=n) + 1                          # the point itself counts
+    core = degree >= min_samples
+    if not core.any():
+        return labels
+    both = core[pairs[:, 0]] & core[pairs[:, 1]]
+    graph = coo_matrix((np.ones(int(both.sum()), dtype=np.int8), (pairs[both, 0], pairs[both, 1])), shape=(n, n))
+    _, comp = connected_components(graph, directed=False)
+    core_idx = np.flatnonzero(core)
+    first_core = np.full(comp.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first_core, comp[core_idx], core_idx)                           # lowest core index of each component
+    order = np.argsort(first_core, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    labels[core_idx] = rank[comp[core_idx]]
+    # border points: earliest cluster among their core neighbours
+    edge = np.concatenate([pairs[core[pairs[:, 1]] & ~core[pairs[:, 0]]],
+                           pairs[core[pairs[:, 0]] & ~core[pairs[:, 1]]][:, ::-1]])   # (border, core)
+    if len(edge):
+        best = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+        np.minimum.at(best, edge[:, 0], labels[edge[:, 1]])
+        hit = best != np.iinfo(np.int64).max
+        labels[hit] = best[hit]
+    return labels
+
+
+def _host_array(a) -> np.ndarray:
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+def handle_stationary_clusters(mpm_solver, positions, material_ids, eps: float = 0.03, min_samples: int = 10,
+                               start_time: float = 0.0, end_time: float = 1e6, buffer: float = 0.0,
+                               only_handle_largest_cluster: bool = True, debug_output_dir=None, debug: bool = False):
+    """material_field.py:364-479: one velocity-zero cuboid (reset=1) around every density cluster of the particles whose
+    material is "stationary" -- or only around the largest one.  Returns the list of BC records the reference returns.
+    (`debug_output_dir` / `debug` are accepted for signature compatibility; the PLY dumps are not reproduced.)"""
+    pos = _host_array(positions)
+    mat = _host_array(material_ids)
+    stationary = pos[mat == STATIONARY_ID]
+    if len(stationary) == 0:
+        return []
+    labels = dbscan_labels(stationary, eps, min_samples)
+    ids = np.unique(labels[labels >= 0])
+    if len(ids) == 0:
+        return []
+    sizes = {int(i): int(np.sum(labels == i)) for i in ids}
+    if only_handle_largest_cluster and len(ids) > 1:
+        ids = np.array([max(sizes.items(), key=lambda kv: kv[1])[0]])            # first maximum, as the reference
+    records = []
+    for cid in ids:
+        cluster = stationary[labels == cid]
+        lo, hi = cluster.min(axis=0), cluster.max(axis=0)
+        center = (0.5 * (lo + hi)).tolist()
+        half = (0.5 * (hi - lo) + buffer).tolist()
+        mpm_solver.set_velocity_on_cuboid(point=center, size=half, velocity=[0.0, 0.0, 0.0], start_time=start_time,
+                                          end_time=end_time, reset=1)
+        records.append({"type": "stationary_cluster", "cluster_id": int(cid), "point": center, "size": half,
+                        "velocity": [0.0, 0.0, 0.0], "start_time": start_time, "end_time": end_time, "reset": 1,
+                        "cluster_size": sizes[int(cid)]})
+    return records
+
+
+def fix_to_ground(mpm_solver, positions, delta_z: float = 0.02, buffer_xy: float = 0.5, min_z_percentile: float = 1,
+                  start_time: float = 0.0, end_time: float = 1e6):
+    """material_field.py:485-550: a thin velocity-zero slab (reset=1) under the point cloud, z taken as up.  `positions`
+    may be a device tensor: the six extrema are reduced where the data lives."""
+    if isinstance(positions, torch.Tensor):
+        lo, hi = positions.amin(dim=0), positions.amax(dim=0)
+        min_xy, max_xy = lo[:2].double().cpu().numpy(), hi[:2].double().cpu().numpy()
+        min_z = float(torch.quantile(positions[:, 2].double(), min_z_percentile / 100.0)) if min_z_percentile > 1 else float(lo[2])
+    else:
+        pos = np.asarray(positions)
+        min_xy, max_xy = pos[:, :2].min(axis=0), pos[:, :2].max(axis=0)
+        min_z = float(np.percentile(pos[:, 2], min_z_percentile)) if min_z_percentile > 1 else float(pos[:, 2].min())
+    size_xy = max_xy - min_xy
+    center = [float(min_xy[0] + max_xy[0]) / 2, float(min_xy[1] + max_xy[1]) / 2, min_z + delta_z / 2]
+    half = [float(size_xy[0]) / 2 + buffer_xy, float(size_xy[1]) / 2 + buffer_xy, delta_z / 2]
+    mpm_solver.set_velocity_on_cuboid(point=center, size=half, velocity=[0.0, 0.0, 0.0], start_time=start_time,
+                                      end_time=end_time, reset=1)
+    return [{"type": "ground", "point": center, "size": half, "velocity": [0.0, 0.0, 0.0], "start_time": start_time,
+             "end_time": end_time, "reset": 1}]
