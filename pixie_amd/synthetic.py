@@ -53,6 +53,17 @@ def mpm_ball_scene(n_particles: int = 100_000, seed: int = 0, n_grid: int = 50, 
         scene["params"] = dict(material="jelly", g=[0.0, 0.0, -9.8], E=4e4, nu=0.4, density=200.0)
         scene["bcs"] = [dict(type="bounding_box")]
         scene["fix_ground"] = None
+    elif scenario == "sand":
+        # PhysGaussian/config/objaverse/custom_sand_config.json: Drucker-Prager sand dropped on a sticky floor inside the
+        # bounding box (n_grid 200, substep 2e-5 in the reference; the caller chooses n_grid / dt)
+        scene["params"] = dict(material="sand", g=[0.0, 0.0, -9.8], E=5e7, nu=0.3, density=2000.0, friction_angle=30.0)
+        scene["bcs"] = [dict(type="bounding_box"),
+                        dict(type="surface_collider", point=[1.0, 1.0, 0.48], normal=[0.0, 0.0, 1.0], surface="sticky", friction=0.0,
+                             start_time=0.0, end_time=1e3)]
+        scene["fix_ground"] = None
+        scene["E"] = np.full(n_particles, 5e7, np.float32); scene["nu"] = np.full(n_particles, 0.3, np.float32)
+        scene["density"] = np.full(n_particles, 2000.0, np.float32)
+        scene["material"] = np.full(n_particles, 2, np.int32)
     else:
         raise ValueError(scenario)
     return scene

@@ -16,7 +16,8 @@ def main():
     n = int(sys.argv[1]); ng = int(sys.argv[2])
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     resort = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    sc = mpm_ball_scene(n, seed=0, n_grid=ng)
+    scenario = os.environ.get("PIXIE_MPM_SCENARIO", "tree")
+    sc = mpm_ball_scene(n, seed=0, n_grid=ng, scenario=scenario, dt=float(os.environ.get("PIXIE_MPM_DT", "1e-4")))
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
@@ -37,7 +38,7 @@ def main():
     p_ms, g_ms, nl = s.kernel_times()
     s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
-    print(f"n={n} ng={ng} resort={resort}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
+    print(f"n={n} ng={ng} resort={resort} {scenario}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
           f"rebins {int(s._get_scalar('n_rebins'))} slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "

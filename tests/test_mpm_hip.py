@@ -262,6 +262,30 @@ def test_full_size_properties(hip_device):
     assert abs(h.time - 500 * sc["dt"]) < 1e-9
 
 
+def test_full_size_sand_config(hip_device):
+    """The reference's plastic-material configuration (custom_sand_config.json: Drucker-Prager sand, n_grid 200,
+    substep 2e-5, bounding box + sticky floor at z = 0.48) with 1M particles: size-independent properties."""
+    n = 1_000_000
+    sc = mpm_ball_scene(n, seed=0, n_grid=200, dt=2e-5, scenario="sand")
+    h = make_hip(sc)
+    z0 = get(h, "x")[:, 2].astype(np.float64)
+    h.run(sc["dt"], 400)
+    x = get(h, "x").astype(np.float64); v = get(h, "v").astype(np.float64)
+    F = get(h, "F_trial").reshape(-1, 3, 3).astype(np.float64)
+    assert np.isfinite(x).all() and np.isfinite(v).all() and np.isfinite(F).all()
+    assert h.out_of_bounds == 0
+    t = 400 * sc["dt"]
+    # free fall until the floor is reached: the bulk has dropped by g t^2 / 2 (8 mm here), nothing has gone through the floor
+    drop = z0 - x[:, 2]
+    high = z0 > 1.0                               # particles that cannot have felt the floor yet
+    assert abs(np.median(drop[high]) - 0.5 * 9.8 * t * t) < 0.15 * 0.5 * 9.8 * t * t
+    assert x[:, 2].min() > 0.48 - 2.0 / 200
+    # Drucker-Prager projection keeps the elastic deformation gradient near the identity for stiff sand
+    J = np.linalg.det(F)
+    assert J.min() > 0.8 and J.max() < 1.2
+    assert int(h._get_scalar("dropped_particles")) == 0
+
+
 def test_export_frame_for_rendering(hip_device):
     """gs_simulation.py:591-600: positions / covariances of the first gs_num particles back in the scene frame, in one
     launch, against a float64 restatement of transformation_utils.py:19-20,108-130 applied to the solver's own exports."""
