@@ -263,6 +263,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
     };
     // ---- MFMA over the taps of one chunk; the A fragments of tap t+1 are fetched during tap t ----
     auto mfma_chunk = [&](int c_base, const uint4* buf) {
+        __builtin_amdgcn_s_setprio(3);   // the MFMA phase issues ahead of a co-resident workgroup's staging (+1 % measured)
         const uint4* ldsHi = buf;
         const uint4* ldsLo = buf + 2 * A.CS;
         const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
                 for (int mb = 0; mb < MB; ++mb) { ah[mb] = ahn[mb]; al[mb] = aln[mb]; }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     if (WS) {
