@@ -581,8 +581,8 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
         }
         if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
         __syncthreads();
-        bp = fmaxf(s_red[0][0], s_red[0][1]); bm = fmaxf(s_red[1][0], s_red[1][1]);
-        if (nthr > 128) { bp = fmaxf(bp, fmaxf(s_red[0][2], s_red[0][3])); bm = fmaxf(bm, fmaxf(s_red[1][2], s_red[1][3])); }
+        bp = s_red[0][0]; bm = s_red[1][0];
+        for (int w = 1; w < (nthr >> 6); ++w) { bp = fmaxf(bp, s_red[0][w]); bm = fmaxf(bm, s_red[1][w]); }
         const float sP = scale_for(bp), sM = scale_for(bm);
         PX_MPM_STAMP(3);
 
@@ -1406,7 +1406,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     int rc = 0;
     S.nbk = (n_grid + kBS - 1) / kBS;
     h->nblocks = S.nbk * S.nbk * S.nbk;
-    const size_t max_items = (n + kWG / 2 - 1) / (kWG / 2) + std::min<size_t>((size_t)h->nblocks, n);   // for the smaller capacity
+    const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)h->nblocks, n);   // for the smallest capacity (64)
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
     rc |= dev_alloc(h, &S.gin, G); rc |= dev_alloc(h, &S.gout, G);
     rc |= dev_alloc(h, &S.oob, 3);
@@ -1542,7 +1542,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
     else if (k == "trace") h->trace = (int)value;
-    else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 128 || value == 256, "item_cap must be 0 (auto), 128 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
+    else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
     return 0;
