@@ -77,6 +77,7 @@ class ConvProfiler:
 
     def __init__(self):
         self.records = []
+        self.variants = []   # (ksize*100 + MB*10 + NB, split-K slices) of each launch: rocprofv3's grouping key
 
     def wrap(self, ops):
         inner = ops.conv
@@ -90,9 +91,22 @@ class ConvProfiler:
             cin = sum(int(p.shape[0]) for p in parts)
             o = out[0] if isinstance(out, tuple) else out   # (output, epilogue channel sums) on the fused-statistics path
             prof.records.append(((cin, cout, ksize, kw.get("stride", 1), bool(kw.get("upsample", False)), tuple(o.shape[1:])), e0, e1))
+            prof.variants.append(ops.last_variant)
             return out
 
+        ops.record_variant = True
         ops.conv = conv
+
+    def by_variant(self):
+        """mean launch duration per kernel instantiation -- what `rocprofv3 --kernel-trace --stats` reports per kernel name
+        (the event pair also brackets the small split-K reduce / statistics launches that follow some convs)"""
+        torch.cuda.synchronize()
+        agg = {}
+        for (key, e0, e1), var in zip(self.records, self.variants):
+            a = agg.setdefault(var, [0.0, 0])
+            a[0] += e0.elapsed_time(e1); a[1] += 1
+        return {f"conv3d_f16x3_kernel<{v // 100},{(v // 10) % 10},{v % 10}>" + (f" x{sl} slices" if sl > 1 else "") if v else "conv3d_mfma_kernel (exact fp32)":
+                {"launches": n, "avg_ms": round(t / n, 4)} for (v, sl), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])}
 
     def summary(self):
         torch.cuda.synchronize()
@@ -166,7 +180,8 @@ def bench_unet(args, rank, world, device):
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
     conv_ms = sum(v[0] for v in agg.values()) / max(args.steps, 1)
     return dict(seconds=dt, voxels=world * args.steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision,
-                conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(args.steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]})
+                conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(args.steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
+                kernel_avg=prof.by_variant())
 
 
 def load_traffic():
@@ -335,6 +350,8 @@ def main():
             if "mpm" in line:
                 line["mpm"]["cpu_baseline"] = cpu["mpm"]
         line["layer_ms_top"] = u["layer_ms"]
+        # per kernel NAME, all shapes pooled: comparable with the avg column of profiles/*_kernel_stats.csv (rocprofv3 --stats)
+        line["conv_kernel_avg_ms"] = u["kernel_avg"]
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

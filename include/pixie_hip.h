@@ -196,6 +196,10 @@ int pixie_conv3d_forward(const pixie_conv_desc* desc, void* stream);
 int64_t pixie_conv_stats_floats(const pixie_conv_desc* desc);
 int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* desc);
 int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* desc, double* d_sums, void* stream);
+/* Which kernel instantiation pixie_conv3d_forward picks for this descriptor: ksize*100 + MB*10 + NB of
+ * conv3d_f16x3_kernel<ksize,MB,NB> (and its split-K factor in *slices), 0 = the exact-fp32 kernel.  For profilers that
+ * want to group per-launch timings by kernel name, as rocprofv3 does; no reference counterpart. */
+int pixie_conv_kernel_variant(const pixie_conv_desc* desc, int* slices);
 
 /* Per-channel sum and sum of squares over the spatial extent: d_sums[2*c] (float64). */
 int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream);

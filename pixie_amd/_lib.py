@@ -95,6 +95,7 @@ SIGNATURES = {
     "pixie_conv3d_forward": (_I, [C.POINTER(ConvDesc), _VP]),
     "pixie_conv_stats_floats": (_I64, [C.POINTER(ConvDesc)]),
     "pixie_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
+    "pixie_conv_kernel_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
     "pixie_stats_finalize": (_I, [_VP, C.POINTER(ConvDesc), _VP, _VP]),
     "pixie_channel_stats": (_I, [_VP, _I, _I64, _VP, _VP, _VP]),
     "pixie_tensor_amax": (_I, [_VP, _I64, _VP, _VP]),

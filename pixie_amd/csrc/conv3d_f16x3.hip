@@ -1020,6 +1020,19 @@ extern "C" int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* d) {
     return slices > 1 ? (int64_t)slices * a.cout * a.OD * a.OH * a.OW * (int64_t)sizeof(float) : 0;
 }
 
+// which kernel instantiation pixie_conv3d_forward picks for this descriptor: variant = ksize * 100 + MB * 10 + NB of
+// conv3d_f16x3_kernel<ksize, MB, NB>, slices = its split-K factor; 0 = the exact-fp32 kernel.  (Lets a profiler group
+// its own per-launch timings the way rocprofv3 groups them: by kernel name.)
+extern "C" int pixie_conv_kernel_variant(const pixie_conv_desc* d, int* slices_out) {
+    if (slices_out) *slices_out = 1;
+    if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
+    Conv16Args a{};
+    int MB = 0, NB = 0, slices = 1;
+    conv16_tiling(d, a, MB, NB, &slices);
+    if (slices_out) *slices_out = slices;
+    return d->ksize * 100 + MB * 10 + NB;
+}
+
 extern "C" int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* d, double* d_sums, void* stream) {
     PX_REQUIRE(d_stats && d && d_sums, "pixie_stats_finalize: null argument");
     // recompute the tile count exactly as conv3d_f16x3_forward does

@@ -49,6 +49,8 @@ class HipOps:
         self.device = device
         self.lib = _lib.load()
         self.split_k = os.environ.get("PIXIE_CONV_SPLIT_K", "1") != "0"
+        self.record_variant = False      # set by profilers (bench.py): conv() then leaves the kernel instantiation in last_variant
+        self.last_variant = (0, 1)
 
     @property
     def stream(self):
@@ -133,6 +135,9 @@ class HipOps:
                 stats = torch.empty(nfl, device=self.device, dtype=torch.float32)
                 desc.d_out_stats = stats.data_ptr()
                 desc.d_out_amax = out_amax.data_ptr()
+        if self.record_variant:   # profilers: which kernel instantiation this launch is (grouping key of rocprofv3)
+            sl = C.c_int(1)
+            self.last_variant = (int(self.lib.pixie_conv_kernel_variant(C.byref(desc), C.byref(sl))), int(sl.value))
         check(self.lib.pixie_conv3d_forward(C.byref(desc), self.stream), "pixie_conv3d_forward")
         if desc.d_out_stats:
             sums = torch.empty((cout, 2), device=self.device, dtype=torch.float64)
