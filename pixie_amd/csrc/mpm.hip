@@ -619,6 +619,8 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
             __syncthreads();
         }
         PX_MPM_STAMP(5);
+        if (DO_G2P && DO_P2G && sp.trace && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
+            g_mpm_trace[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 }
 

@@ -40,3 +40,19 @@ for i, nm in enumerate(names):
     print(f"  {nm:42s} {d.mean():6.2f} us  (p10 {np.percentile(d, 10):6.2f}, p90 {np.percentile(d, 90):6.2f})")
 start = np.sort(us[:, 0])
 print("  start times: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us" % tuple(np.percentile(start, [10, 50, 90, 100])))
+
+# ---- placement: workgroups per CU and lifetime by co-residency
+hw = buf.reshape(m, 8)[:, 6]
+cu = ((hw >> np.uint64(8)) & np.uint64(0xF)).astype(int); se = ((hw >> np.uint64(13)) & np.uint64(0x7)).astype(int)
+sh = ((hw >> np.uint64(12)) & np.uint64(0x1)).astype(int); xcc = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(int)
+key = xcc * 10000 + se * 100 + sh * 50 + cu
+life = us[:, 5] - us[:, 0]
+first = us[:, 0] < 2.0           # first dispatch round
+uk, cnt = np.unique(key[first], return_counts=True)
+print(f"first round: {first.sum()} workgroups on {len(uk)} CUs; workgroups per CU: " + ", ".join(f"{c}: {int((cnt == c).sum())} CUs" for c in np.unique(cnt)))
+per = dict(zip(uk, cnt))
+co = np.array([per.get(k, 0) for k in key])
+for c in np.unique(co[first]):
+    sel = first & (co == c)
+    print(f"  {c} workgroup(s) on the CU: lifetime mean {life[sel].mean():6.2f} us, max {life[sel].max():6.2f} (n={sel.sum()})")
+print(f"  particles per item: mean {n / items:.0f}")
