@@ -65,6 +65,7 @@ struct MpmPtrs {
     const int2* blk_items;       // per block: (first work item, number of work items)
     int* blk_flags;              // per block: bit 0 = active (particles nearby), bit 1 = slow-path particles wrote into gin here
     const int* active_list;      // the active blocks
+    const int2* nbr_table;       // per active block (same order): [0] = (block id, 0), [1..27] = blk_items of its 27 neighbours
     unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles,
                                  // [2] slow-path particles dropped because they had left every active block
 };
@@ -749,7 +750,8 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
 // blk_flags bit 0 <- "one of my 27 neighbours holds particles", and the compact list of those ACTIVE blocks: the only
 // ones the grid kernel is launched for (workgroup dispatch alone costs ~10 us for the 27000 blocks of a 120^3 grid).
 __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restrict__ counts, int* __restrict__ blk_flags,
-                                                              int* __restrict__ active_list, int* __restrict__ n_active, int nbk) {
+                                                              int* __restrict__ active_list, int* __restrict__ n_active, int nbk,
+                                                              const int2* __restrict__ blk_items, int2* __restrict__ nbr_table) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbk * nbk * nbk) return;
     const int bz = b % nbk, by = (b / nbk) % nbk, bx = b / (nbk * nbk);
@@ -762,7 +764,18 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
                     active = active || counts[(x * nbk + y) * nbk + z] > 0;
             }
     blk_flags[b] = active ? 1 : 0;
-    if (active) active_list[atomicAdd(n_active, 1)] = b;
+    if (!active) return;
+    const int slot = atomicAdd(n_active, 1);
+    active_list[slot] = b;
+    // everything the grid kernel needs to find this block's tiles, in one 224-byte row: one memory round trip there
+    // instead of active_list -> blk_items -> tiles
+    int2* row = nbr_table + (size_t)slot * 28;
+    row[0] = make_int2(b, 0);
+    for (int q = 0; q < 27; ++q) {
+        const int x = bx + q / 9 - 1, y = by + (q / 3) % 3 - 1, z = bz + q % 3 - 1;
+        const bool in = (unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk;
+        row[1 + q] = in ? blk_items[(x * nbk + y) * nbk + z] : make_int2(0, 0);
+    }
 }
 
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
@@ -882,22 +895,31 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
 // inactive blocks are skipped entirely (mode 0); their grid_v_out is brought up to date on demand (mode 1, used by
 // the grid_v_out export) with the parameters of the last update, which for a massless node is just the BCs on v = 0.
 __global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
-    const int blk = (mode == 0) ? S.active_list[blockIdx.x] : (int)blockIdx.x;
+    int blk = (int)blockIdx.x;
+    int2 mine = make_int2(0, 0);
+    if (mode == 0) {   // one coalesced row: block id + the work items of the 27 neighbours (lane q holds neighbour q)
+        const int lane = threadIdx.x;
+        const int2 row = (lane < 28) ? S.nbr_table[(size_t)blockIdx.x * 28 + lane] : make_int2(0, 0);
+        blk = __shfl(row.x, 0);
+        mine.x = __shfl(row.x, (lane + 1) & 63); mine.y = __shfl(row.y, (lane + 1) & 63);
+    }
     const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
     const int flag = S.blk_flags[blk];  // bit 0: active (set at re-binning); bit 1: slow-path writes
-    if (mode == 1 && (flag & 1)) return;
-    const int2 mine = neighbour_items(S, Bx, By, Bz);
+    if (mode == 1) {
+        if (flag & 1) return;
+        mine = neighbour_items(S, Bx, By, Bz);
+    }
     const int lx = threadIdx.x >> 4, ly = (threadIdx.x >> 2) & 3, lz = threadIdx.x & 3;
     const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
     const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode == 0) {
+        g = gather_node(S, mine, lx, ly, lz, g);   // does not wait for the flag
         if (flag & 2) {  // slow-path particles added fp32 atomics into gin here
-            if (inside) { g = S.gin[idx]; S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            if (inside) { const float4 q = S.gin[idx]; g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w; S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
             if (threadIdx.x == 0) S.blk_flags[blk] = flag & 1;
         }
-        g = gather_node(S, mine, lx, ly, lz, g);
     }
     if (!inside) return;
     float v[3] = {0.0f, 0.0f, 0.0f};
@@ -1149,6 +1171,7 @@ struct pixie_mpm {
     bool pending_p2g = false;                // staged tiles not yet consumed by the grid kernel
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
+    int2* nbr_table = nullptr;               // 28 int2 per active block (see MpmPtrs)
     int n_active = 0;
     bool gout_sparse = false;                // inactive blocks of gout are stale (refreshed on export)
     StepParams last_grid_sp{};
@@ -1183,7 +1206,7 @@ void bind_rows(pixie_mpm* h) {
     S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
     S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n;
-    S.items = h->items; S.part = h->part; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list;
+    S.items = h->items; S.part = h->part; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -1202,7 +1225,7 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, h->item_cap);
     PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 1, 0, sizeof(int), st));
     hipLaunchKernelGGL(bin_mark_active_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->counts, h->blk_flags, h->active_list,
-                       h->d_n_items + 1, S.nbk);  // (rewrites every flag: no slow-path writes are pending here)
+                       h->d_n_items + 1, S.nbk, h->blk_items, h->nbr_table);  // (rewrites every flag: no slow-path writes are pending here)
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
     // keys/rank are free again: reuse them as the local kernel's scratch
     hipLaunchKernelGGL(bin_local_order_kernel, dim3((unsigned)h->nblocks), dim3(256), 0, st, S, h->counts, h->offsets, h->order, h->keys,
@@ -1416,6 +1439,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks);
     rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 4);
     rc |= dev_alloc(h, &h->active_list, (size_t)h->nblocks);
+    rc |= dev_alloc(h, &h->nbr_table, (size_t)h->nblocks * 28);
     rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks); rc |= dev_alloc(h, &h->blk_flags, (size_t)h->nblocks); rc |= dev_alloc(h, &h->part, max_items * kTN);
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
