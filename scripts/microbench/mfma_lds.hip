@@ -12,12 +12,14 @@ __device__ __forceinline__ unsigned rnd_half2(unsigned x) {   // two fp16 values
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return (x & 0x83ff83ffu) | 0x3c003c00u;
 }
+// random = 2 / 3: the `lo` operands keep only their top 3 / 0 mantissa bits (how much of the power limit is the lo terms?)
+__device__ __host__ inline unsigned lomask(bool is_lo, int random) { return (!is_lo || random < 2) ? 0xffffffffu : (random == 2 ? 0xff80ff80u : 0xfc00fc00u); }
 template <int MODE, int OCC>
 __global__ __launch_bounds__(256, OCC) void k(const uint4* __restrict__ w, float* __restrict__ out, int taps, int lds_units, int random) {
     extern __shared__ uint4 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < lds_units; i += 256)
-        lds[i] = random ? make_uint4(rnd_half2(4 * i), rnd_half2(4 * i + 1), rnd_half2(4 * i + 2), rnd_half2(4 * i + 3))
+        lds[i] = random ? make_uint4(rnd_half2(4 * i) & lomask(i >= 600, random), rnd_half2(4 * i + 1) & lomask(i >= 600, random), rnd_half2(4 * i + 2) & lomask(i >= 600, random), rnd_half2(4 * i + 3) & lomask(i >= 600, random))
                         : make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
     __syncthreads();
     f32x16 acc[2][4];
@@ -83,6 +85,11 @@ int main() {
         run<3, 2>("RANDOM data: B from LDS + A from global, 2 WG/CU", wr, out, 2048, 78 * 1024, 1);
         run<3, 1>("RANDOM data: B from LDS + A from global, 1 WG/CU", wr, out, 1024, 156 * 1024, 1);
         run<0, 1>("RANDOM data: B in registers, 1 WG/CU", wr, out, 1024, 156 * 1024, 1);
+        for (int mode = 2; mode <= 3; ++mode) {
+            for (int i = 0; i < 8192 * 4; ++i) if (((i / 4) % 256) >= 128) h[i] &= lomask(true, mode);
+            CK(hipMemcpy(wr, h, 8192 * 16, hipMemcpyHostToDevice));
+            run<3, 2>(mode == 2 ? "RANDOM hi, lo operands 3 mantissa bits, 2 WG/CU" : "RANDOM hi, lo operands 0 mantissa bits, 2 WG/CU", wr, out, 2048, 78 * 1024, mode);
+        }
     }
     run<4, 2>("  ... + 2 barriers per 27 taps, 2 WG/CU", w, out, 2048, 78 * 1024);
     run<0, 2>("B in registers, 4 WG/CU (32 KB LDS each)", w, out, 4096, 32 * 1024);
