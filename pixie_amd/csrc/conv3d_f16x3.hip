@@ -12,7 +12,7 @@
 //
 // Replaces the same reference ops as conv3d_mfma.hip (WG/models/module/diffusion_network.py conv_nd at
 // :679,:683,:691,:762,:58,:206,:208,:872, FeatureProjector :570-583) for stride-1 layers whose channel counts are
-// multiples of 16; everything else (stride 2, tiny test networks) stays on the exact-fp32 kernel.
+// multiples of 16 (stride 2 for the 3^3 Downsample convs); everything else (tiny test networks) stays on the exact-fp32 kernel.
 //
 // Formulation: Out[co][v] = sum_{tap,ci} W[tap][ci][co] X[ci][v+tap], implicit GEMM with M = c_out (A operand),
 // N = voxels (B operand, 32 x-contiguous voxels per MFMA column block), K = taps*c_in walked tap by tap in steps
@@ -53,6 +53,7 @@ struct Conv16Args {
     int ID, IH, IW;          // stored input dims
     int LD, LH, LW;          // logical input dims (after optional nearest x2)
     int ups;
+    int stride;              // 1, or 2 (3^3 Downsample convs: the LDS tile then holds every input voxel, the B reads skip one)
     int OD, OH, OW;
     const float* pro_a; const float* pro_b; const float* gamma; const float* beta;
     int act;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
     const int tz = t / A.tiles_y;
     const int ox0 = tx * A.TX, oy0 = ty * A.TY, oz0 = tz * A.TZ;
     const int cout0 = blockIdx.y * (MB * 32);
-    const int lx0 = ox0 - PAD, ly0 = oy0 - PAD, lz0 = oz0 - PAD;
+    const int lx0 = ox0 * A.stride - PAD, ly0 = oy0 * A.stride - PAD, lz0 = oz0 * A.stride - PAD;
     const size_t ISP = (size_t)A.ID * A.IH * A.IW;
     const size_t OSP = (size_t)A.OD * A.OH * A.OW;
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16A
         int z = j >> (A.lTX + A.lTY);
         const bool v = (z < A.TZ) && (ox0 + x < A.OW) && (oy0 + y < A.OH) && (oz0 + z < A.OD);
         if (!v) { x = 0; y = 0; z = 0; }
-        voff[nb] = (z * A.HY + y) * A.HX + x + kh * A.CS;
+        voff[nb] = ((z * A.HY + y) * A.HX + x) * A.stride + kh * A.CS;
         ovox[nb] = ((oz0 + z) * A.OH + (oy0 + y)) * A.OW + ox0 + x;
         valid[nb] = v;
     }
@@ -851,11 +852,12 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
     a.ups = d->upsample;
     a.LD = a.ID << a.ups; a.LH = a.IH << a.ups; a.LW = a.IW << a.ups;
     const int pad = d->ksize == 3 ? 1 : 0;
-    a.OD = a.LD + 2 * pad - d->ksize + 1; a.OH = a.LH + 2 * pad - d->ksize + 1; a.OW = a.LW + 2 * pad - d->ksize + 1;
+    a.stride = d->stride;
+    a.OD = (a.LD + 2 * pad - d->ksize) / a.stride + 1; a.OH = (a.LH + 2 * pad - d->ksize) / a.stride + 1; a.OW = (a.LW + 2 * pad - d->ksize) / a.stride + 1;
     a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     const long ovol = (long)a.OD * a.OH * a.OW;
     int MB = (a.coutp >= 64) ? 2 : 1;
-    int NB = 4;
+    int NB = (a.stride == 2) ? 1 : 4;   // stride 2: the tile holds 8x the voxels it produces; only NB = 1 fits (112 KB, one workgroup per CU)
     auto n_wg = [&](int mb, int nb) {
         const long tiles = (ovol + 128L * nb - 1) / (128L * nb);
         return tiles * ((a.coutp + mb * 32 - 1) / (mb * 32));
@@ -868,7 +870,7 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
     const int smax = d->d_workspace ? std::min(8, chunks / 2) : 1;
     if (smax >= 2 && n_wg(MB, NB) < 512) {
         bool found = false;
-        for (int nb = 4; nb >= 1 && !found; nb /= 2) {
+        for (int nb = NB; nb >= 1 && !found; nb /= 2) {
             for (int sl = 1; sl <= smax; sl *= 2)
                 if (n_wg(MB, nb) * sl >= 512) { NB = nb; slices = sl; found = true; break; }
         }
@@ -886,7 +888,7 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
     a.lTX = ilog2_16(a.TX); a.lTY = ilog2_16(a.TY);
     a.tiles_x = (a.OW + a.TX - 1) / a.TX; a.tiles_y = (a.OH + a.TY - 1) / a.TY; a.tiles_z = (a.OD + a.TZ - 1) / a.TZ;
     a.n_tiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    a.HX = a.TX - 1 + d->ksize; a.HY = a.TY - 1 + d->ksize; a.HZ = a.TZ - 1 + d->ksize;
+    a.HX = (a.TX - 1) * a.stride + d->ksize; a.HY = (a.TY - 1) * a.stride + d->ksize; a.HZ = (a.TZ - 1) * a.stride + d->ksize;
     a.HYX = a.HY * a.HX; a.CS = a.HZ * a.HYX;
     a.mHX = magic_of16(a.HX); a.mHYX = magic_of16(a.HYX);
 
@@ -903,7 +905,7 @@ void conv_set_pipe(bool on) { g_conv_no_pipe = !on; }
 
 // called by pixie_conv3d_forward (conv3d_mfma.hip) when the descriptor carries f16x2-packed weights
 int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
-    PX_REQUIRE(d->stride == 1, "f16x3 conv: stride must be 1");
+    PX_REQUIRE(d->stride == 1 || (d->stride == 2 && d->ksize == 3 && !d->upsample), "f16x3 conv: stride must be 1, or 2 for a 3^3 kernel");
     const int cin = d->c0 + d->c1;
     PX_REQUIRE(cin % 16 == 0 && d->c0 % 8 == 0, "f16x3 conv: c_in must be a multiple of 16 (got %d+%d)", d->c0, d->c1);
     PX_REQUIRE(d->d_in_amax0 != nullptr || d->in_bound > 0.0f, "f16x3 conv: needs d_in_amax0 or a positive in_bound");
@@ -914,7 +916,8 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     a.ups = d->upsample;
     a.LD = a.ID << a.ups; a.LH = a.IH << a.ups; a.LW = a.IW << a.ups;
     const int pad = d->ksize == 3 ? 1 : 0;
-    a.OD = a.LD + 2 * pad - d->ksize + 1; a.OH = a.LH + 2 * pad - d->ksize + 1; a.OW = a.LW + 2 * pad - d->ksize + 1;
+    a.stride = d->stride;
+    a.OD = (a.LD + 2 * pad - d->ksize) / a.stride + 1; a.OH = (a.LH + 2 * pad - d->ksize) / a.stride + 1; a.OW = (a.LW + 2 * pad - d->ksize) / a.stride + 1;
     a.pro_a = d->d_pro_a; a.pro_b = d->d_pro_b; a.gamma = d->d_gamma; a.beta = d->d_beta; a.act = d->act;
     a.w16 = reinterpret_cast<const uint4*>(d->d_w16); a.bias = d->d_bias; a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     a.residual = d->d_residual; a.out = d->d_out;
@@ -1002,7 +1005,7 @@ extern "C" int pixie_set_option(const char* key, int value) {
 
 // number of floats of the epilogue statistics buffer for this descriptor (0 if the layer does not take the f16x3 path)
 extern "C" int64_t pixie_conv_stats_floats(const pixie_conv_desc* d) {
-    if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
+    if (!d || !d->d_w16 || !(d->stride == 1 || (d->stride == 2 && d->ksize == 3)) || (d->ksize != 1 && d->ksize != 3)) return 0;
     Conv16Args a{};
     int MB = 0, NB = 0, slices = 1;
     conv16_tiling(d, a, MB, NB, &slices);
@@ -1011,7 +1014,7 @@ extern "C" int64_t pixie_conv_stats_floats(const pixie_conv_desc* d) {
 
 // bytes of d_workspace this layer can use for split-K (0: it would not split).  Decided on the shape alone.
 extern "C" int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* d) {
-    if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
+    if (!d || !d->d_w16 || !(d->stride == 1 || (d->stride == 2 && d->ksize == 3)) || (d->ksize != 1 && d->ksize != 3)) return 0;
     pixie_conv_desc probe = *d;
     probe.d_workspace = reinterpret_cast<void*>(1);   // "a workspace would be available"
     Conv16Args a{};
@@ -1025,7 +1028,7 @@ extern "C" int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* d) {
 // its own per-launch timings the way rocprofv3 groups them: by kernel name.)
 extern "C" int pixie_conv_kernel_variant(const pixie_conv_desc* d, int* slices_out) {
     if (slices_out) *slices_out = 1;
-    if (!d || !d->d_w16 || d->stride != 1 || (d->ksize != 1 && d->ksize != 3)) return 0;
+    if (!d || !d->d_w16 || !(d->stride == 1 || (d->stride == 2 && d->ksize == 3)) || (d->ksize != 1 && d->ksize != 3)) return 0;
     Conv16Args a{};
     int MB = 0, NB = 0, slices = 1;
     conv16_tiling(d, a, MB, NB, &slices);

@@ -82,7 +82,7 @@ class HipOps:
     @staticmethod
     def f16x3_ok(parts: Sequence[torch.Tensor], stride: int) -> bool:
         cin = sum(int(p.shape[0]) for p in parts)
-        return stride == 1 and cin % 16 == 0 and int(parts[0].shape[0]) % 8 == 0
+        return stride in (1, 2) and cin % 16 == 0 and int(parts[0].shape[0]) % 8 == 0   # stride 2: the 3^3 Downsample convs
 
     def conv(self, parts: Sequence[torch.Tensor], packed_w: Optional[torch.Tensor], bias: Optional[torch.Tensor], cout: int, ksize: int,
              stride: int = 1, upsample: bool = False, pro: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,

@@ -106,7 +106,7 @@ class TorchRefOpsF16x3(TorchRefOps):
     @staticmethod
     def f16x3_ok(parts, stride):
         cin = sum(int(p.shape[0]) for p in parts)
-        return stride == 1 and cin % 16 == 0 and int(parts[0].shape[0]) % 8 == 0
+        return stride in (1, 2) and cin % 16 == 0 and int(parts[0].shape[0]) % 8 == 0
 
     def channel_stats(self, x, amax_slot):
         amax_slot.copy_(x.abs().max().reshape(1).float().view(torch.int32))
@@ -152,7 +152,8 @@ class TorchRefOpsF16x3(TorchRefOps):
             xh = F.interpolate(xh[None], scale_factor=2, mode="nearest")[0]
             xl = F.interpolate(xl[None], scale_factor=2, mode="nearest")[0]
         pad = 1 if ksize == 3 else 0
-        y = F.conv3d(xl[None], wh, None, padding=pad) + F.conv3d(xh[None], wl, None, padding=pad) + F.conv3d(xh[None], wh, None, padding=pad)
+        y = (F.conv3d(xl[None], wh, None, stride=stride, padding=pad) + F.conv3d(xh[None], wl, None, stride=stride, padding=pad)
+             + F.conv3d(xh[None], wh, None, stride=stride, padding=pad))
         y = y[0] * (2.0 ** (-ex - ew))
         if bias is not None:
             y = y + bias[:, None, None, None]
