@@ -12,18 +12,19 @@ from pixie_amd.unet import ACT_LEAKY, HipOps  # noqa: E402
 dev = torch.device("cuda:0")
 ops = HipOps(dev)
 g = torch.Generator().manual_seed(0)
-cin, cout, D = 64, 64, 128
+cin, cout, D = int(os.environ.get("CONV_CIN", "64")), int(os.environ.get("CONV_COUT", "64")), 128
+K = int(os.environ.get("CONV_K", "3"))
 x = torch.randn((cin, D, D, D), generator=g).to(dev)
-w = (torch.randn((cout, cin, 3, 3, 3), generator=g) / (cin * 27) ** 0.5).to(dev)
+w = (torch.randn((cout, cin, K, K, K), generator=g) / (cin * K ** 3) ** 0.5).to(dev)
 b = torch.randn(cout, generator=g).to(dev)
 pro = (torch.ones(cin, device=dev), torch.zeros(cin, device=dev))
 aff = (torch.ones((D, D, D), device=dev), torch.zeros((D, D, D), device=dev))
 kw = dict(pro=pro, affine=aff, act=ACT_LEAKY, in_bound=64.0, w16=ops.pack_conv16(w))
 extra = int(os.environ.get("PIXIE_CONV_DBG", "0"))
 for _ in range(2):
-    ops.conv([x], None, b, cout, 3, **kw)
+    ops.conv([x], None, b, cout, K, **kw)
 ops.lib.pixie_set_option(b"conv_dbg", 4 | extra)
-ops.conv([x], None, b, cout, 3, **kw)
+ops.conv([x], None, b, cout, K, **kw)
 torch.cuda.synchronize()
 ops.lib.pixie_set_option(b"conv_dbg", 0)
 n_wg, words = 4096, 16
