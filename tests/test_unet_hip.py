@@ -404,6 +404,36 @@ def test_predict_material_field_and_batch(hip_device):
     assert np.isfinite(phys).all() and phys[1].min() >= 10 ** 3.0
 
 
+def test_full_size_network_two_independent_executions_agree(hip_device):
+    """BASELINE config 2 (128^3 x 64, both networks, 27 TFLOP): no CPU oracle finishes at this size, so the same
+    networks are executed twice on the device by two independent kernel families -- the f16x3 path (split-fp16 MFMA,
+    fused statistics, split-K) and the exact-fp32 MFMA path (separate statistics passes) -- and must agree; plus the
+    properties of the combined field (finite, exactly one class per voxel, argmax of the logits)."""
+    from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
+    D = 128
+    kw = dict(feature_channels=64, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4),
+              attention_resolutions=(), grid_size=D)
+    seg, cont = SegmentationUNet(num_classes=8, **kw), RegressionUNet(out_channels=3, **kw)
+    seg.load_numpy_state(synthetic_state_dict(seg.cfg, 0))
+    cont.load_numpy_state(synthetic_state_dict(cont.cfg, 1000))
+    seg, cont = seg.to(hip_device).eval(), cont.to(hip_device).eval()
+    g = torch.Generator(device=hip_device).manual_seed(5)
+    feat = torch.randn((1, 64, D, D, D), generator=g, device=hip_device).half().float()
+    res = {}
+    for prec in ("f16x3", "f32"):
+        seg.conv_precision = cont.conv_precision = prec
+        combined, seg_pred, logits, cpred = predict_material_field(seg, cont, feat)
+        assert bool(torch.isfinite(combined).all())
+        assert bool((combined[0, 3:].sum(0) == 1).all())
+        assert torch.equal(seg_pred[0].long(), logits[0].argmax(0))
+        res[prec] = (logits.clone(), cpred.clone(), seg_pred.clone())
+    e_seg = float((res["f16x3"][0] - res["f32"][0]).norm() / res["f32"][0].norm())
+    e_cont = float((res["f16x3"][1] - res["f32"][1]).norm() / res["f32"][1].norm())
+    agree = float((res["f16x3"][2] == res["f32"][2]).float().mean())
+    print(f"128^3 f16x3 vs exact-fp32 execution: logits rel-L2 {e_seg:.2e}, regression rel-L2 {e_cont:.2e}, argmax agreement {agree:.6f}")
+    assert e_seg < 1e-4 and e_cont < 1e-4 and agree > 0.999
+
+
 def test_cpu_tensors_are_rejected(hip_device):
     from pixie_amd._lib import PixieHipError
     from pixie_amd.unet import RegressionUNet
