@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mpm", action="store_true")
     ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="torch.distributed backend for --gpus N > 1 (default nccl = RCCL over xGMI; gloo only for --launcher-selftest)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU-only check of the multi-process path (self-launch, rendezvous, barrier, max-over-ranks timing, "
+                         "field all-gather) on a tiny synthetic field; runs no kernel and reports no throughput")
     ap.add_argument("--conv-precision", choices=["f16x3", "f32"], default=None,
                     help="f16x3 (default): fp32 operands split into fp16 hi+lo, 3 f16 MFMAs per product, fp32 accumulate; "
                          "f32: exact-fp32 MFMA everywhere")
@@ -301,14 +306,69 @@ def cpu_baselines(args):
     return out
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start one process per GPU ourselves, as the reference's
+    inference program does with mp.spawn (WG/trainer/inference_combined.py:335-353).  Re-executes this file under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1, a free port) with the same arguments; the
+    ranks' stdout passes through, so exactly one JSON line (rank 0's) is printed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args, rank, world):
+    """The N > 1 control path without a device: rendezvous, barrier, max-over-ranks timing, the field all-gather in its
+    wire format, scene -> rank mapping.  Prints the same single JSON line shape (no throughput claim)."""
+    import torch.distributed as dist
+    D = 8
+    mine = pd.shard_scenes(world, rank, world)
+    cont = torch.stack([torch.full((3, D, D, D), float(s)) for s in mine])
+    seg = torch.stack([torch.full((D, D, D), s % 8, dtype=torch.int32) for s in mine])
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g_cont, g_seg = pd.all_gather_fields(cont, seg)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    order = pd.unshard_order(world, world)
+    ok = all(float(g_cont[order[i], 0, 0, 0, 0]) == float(i) and int(g_seg[order[i], 0, 0, 0]) == i % 8 for i in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest (no kernels)", "value": None, "unit": None, "n_gpus": world, "world": world,
+                          "collective_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                          "backend": dist.get_backend() if dist.is_initialized() else None, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "gather_ok": bool(ok)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.launcher_selftest:
+        rank, world, local = pd.init_process_group(args.backend or "gloo")
+        raise SystemExit(launcher_selftest(args, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (pixie_amd has no CPU path)")
-    rank, world, local = pd.init_process_group()
-    if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    rank, world, local = pd.init_process_group(args.backend)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -327,7 +387,10 @@ def main():
         vps = u["voxels"] / u["seconds"]
         line = {
             "metric": "voxels/s (128^3 U-Net fwd) + MPM particle-steps/s",
-            "value": vps, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": vps, "unit": "voxels/s", "n_gpus": world, "world": world,
+            "collective_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "backend": (torch.distributed.get_backend() + " (RCCL)") if world > 1 else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * u["seconds"] / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if u["precision"] == "f32" else "f32 (operands split fp16 hi+lo, 3 f16 MFMAs/product, fp32 accumulate)",
             "data": "synthetic",

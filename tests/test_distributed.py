@@ -62,3 +62,21 @@ def test_single_process_passthrough():
     cont = torch.randn(2, 3, 4, 4, 4); seg = torch.randint(0, 8, (2, 4, 4, 4))
     c, s = pd.all_gather_fields(cont, seg)
     assert torch.equal(c, cont) and s.dtype == torch.uint8 and torch.equal(s.long(), seg)
+
+
+def test_bench_self_launch_gloo_world2():
+    """`python bench.py --gpus 2` with no launcher must spawn its own ranks (the first scaling run must not die
+    on a launcher error).  --launcher-selftest exercises exactly that path on CPU: self-launch under torch.distributed.run,
+    gloo rendezvous on 127.0.0.1, barrier, max-over-ranks timing and the field all-gather; one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--launcher-selftest", "--backend", "gloo"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world"] == 2 and rec["collective_ranks"] == 2 and rec["backend"] == "gloo" and rec["gather_ok"]
