@@ -47,6 +47,10 @@ typedef struct pixie_mpm pixie_mpm;
  * grid state for n_particles and an n_grid^3 grid over [0,grid_lim]^3; v=0, C=0, F_trial=I. */
 int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_lim);
 int pixie_mpm_destroy(pixie_mpm* h);
+/* set_parameters_dict with a new n_grid / grid_lim after the particles were loaded (mpm_solver_warp.py:315-342): the
+ * reference re-allocates grid_m / grid_v_in / grid_v_out and recomputes dx, inv_dx; particle state, model scalars,
+ * boundary conditions, particle modifiers and the time are untouched.  Same here, in place.  Synchronises `stream`. */
+int pixie_mpm_regrid(pixie_mpm* h, int n_grid, double grid_lim, void* stream);
 
 /* Field import/export in the reference's AoS layouts (warp_utils.py:42-74):
  *   "x","v": float[n][3]; "F","F_trial","C","stress": float[n][9] row-major;
@@ -122,8 +126,11 @@ int pixie_mpm_export_R(pixie_mpm* h, float* d_R /* [n][9] */, void* stream);
 int pixie_mpm_export_frame(pixie_mpm* h, int n_out, const double shift[3], double scale, const double mean[3],
                            const double inv_rotation[9], float* d_pos /* [n_out][3] */, float* d_cov /* [n_out][6] or NULL */,
                            void* stream);
-/* Particles whose 3x3x3 stencil left the grid (undefined behaviour in the reference; skipped here).
- * Synchronises `stream`. */
+/* Particles whose 3x3x3 stencil left the grid (undefined behaviour in the reference).  Here such a particle is frozen
+ * (selection <- 2: it neither moves nor scatters mass again) and counted ONCE; slow-path particles that drifted out of
+ * every active block between two re-binnings are dropped from that substep's P2G and counted too.  Synchronises
+ * `stream`.  pixie_mpm_get_scalar("lost_particles_seen") returns the same count as of the last re-binning without
+ * synchronising (the Python shim warns when it becomes non-zero). */
 int pixie_mpm_out_of_bounds(pixie_mpm* h, int64_t* count, void* stream);
 /* Average duration in ms of the fused particle kernel / grid kernel over the launches since the
  * last call, measured with HIP events on `stream` (enable with set_scalar "profile"=1). */

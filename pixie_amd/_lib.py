@@ -71,6 +71,7 @@ SIGNATURES = {
     "pixie_set_option": (_I, [_S, _I]),
     "pixie_mpm_create": (_I, [C.POINTER(_VP), _I, _I, _D]),
     "pixie_mpm_destroy": (_I, [_VP]),
+    "pixie_mpm_regrid": (_I, [_VP, _I, _D, _VP]),
     "pixie_mpm_set_field": (_I, [_VP, _S, _VP, _I64, _VP]),
     "pixie_mpm_get_field": (_I, [_VP, _S, _VP, _I64, _VP]),
     "pixie_mpm_fill_field": (_I, [_VP, _S, _D, _VP]),

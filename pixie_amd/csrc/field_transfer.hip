@@ -56,7 +56,7 @@ __device__ __forceinline__ void voxel_props(const FieldArgs& A, long v, float& d
         const float p = A.pred[(3 + c) * S + v];
         if (p > conf) { conf = p; mid = c; }
     }
-    if (A.ncls <= 1) conf = 1.0f;
+    if (A.ncls <= 1) { mid = (int)A.pred[3 * S + v]; conf = 1.0f; }   // a single class channel IS the class index (get_mat_id, map_pred_to_coords.py:122-126)
 }
 
 // numpy's float32 pairwise sum for n <= 128 (what np.mean does on a float32 array): 8 running sums, then the tail

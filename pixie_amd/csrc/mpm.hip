@@ -368,6 +368,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         const Stencil st = make_stencil(x[0], x[1], x[2], S.inv_dx);
         if (!stencil_inside(st, S.ng)) {
             atomicAdd(S.oob, 1ull);
+            S.selection[p] = 2;   // left the grid: frozen from now on and counted once (UB in the reference)
             return;
         }
         const Mat3& Fold = L.F;
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S,
             st = make_stencil(in.x[0], in.x[1], in.x[2], S.inv_dx);
             if (!stencil_inside(st, ng)) {
                 atomicAdd(S.oob, 1ull);
+                S.selection[it.y + q] = 2;
                 in.active = false;
             } else {
                 const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
@@ -1163,6 +1165,7 @@ struct pixie_mpm {
     int trace = 0;
     bool resort_auto = true;                 // adapt resort_interval to the observed drift (off once the caller sets it)
     unsigned long long slow_at_rebin = 0;
+    unsigned long long lost_seen = 0;        // oob[0] + oob[2] as read back at the last re-binning
     int2* blk_items = nullptr;               // per block: (first work item, item count)
     int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
@@ -1178,6 +1181,7 @@ struct pixie_mpm {
     std::vector<BCDev> last_grid_bcs;
     long n_sorts = 0;
     std::vector<void*> allocs;
+    std::vector<void*> grid_allocs;          // everything sized by n_grid (re-made by pixie_mpm_regrid)
     bool dirty_grid = false;                 // gin holds an un-consumed P2G (phase API)
     // profiling
     bool profile = false;
@@ -1187,11 +1191,11 @@ struct pixie_mpm {
 namespace {
 
 template <typename T>
-int dev_alloc(pixie_mpm* h, T** ptr, size_t count) {
+int dev_alloc(pixie_mpm* h, T** ptr, size_t count, bool grid_sized = false) {
     void* p = nullptr;
     PX_CHECK_HIP(hipMalloc(&p, count * sizeof(T)));
     PX_CHECK_HIP(hipMemset(p, 0, count * sizeof(T)));
-    h->allocs.push_back(p);
+    (grid_sized ? h->grid_allocs : h->allocs).push_back(p);
     *ptr = static_cast<T*>(p);
     return 0;
 }
@@ -1236,7 +1240,14 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     PX_CHECK_HIP(hipGetLastError());
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 4, h->S.oob + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 8, h->S.oob, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 10, h->S.oob + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipStreamSynchronize(st));
+    {   // particles lost so far (left the grid / left every active block), as of this re-binning: free to read, no extra sync
+        unsigned long long a, b;
+        memcpy(&a, h->h_n_items + 8, sizeof a); memcpy(&b, h->h_n_items + 10, sizeof b);
+        h->lost_seen = a + b;
+    }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
     // Cadence: the LDS tile tolerates one cell of drift, and the measured drift of the interval just finished
@@ -1415,6 +1426,36 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
     return 0;
 }
 
+// Everything whose size depends on n_grid: the two grid arrays, the block tables and the work list / staged tiles.
+// Used by pixie_mpm_create and by pixie_mpm_regrid (set_parameters_dict changing n_grid / grid_lim after the particles
+// were loaded, mpm_solver_warp.py:315-342: the reference re-allocates the grids and recomputes dx, nothing else).
+int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
+    MpmPtrs& S = h->S;
+    for (void* p : h->grid_allocs) (void)hipFree(p);
+    h->grid_allocs.clear();
+    S.ng = n_grid;
+    h->grid_lim = grid_lim;
+    S.dx = (float)(grid_lim / n_grid);              // mpm_solver_warp.py:62-66, :320-326
+    S.inv_dx = (float)((double)n_grid / grid_lim);
+    S.nbk = (n_grid + kBS - 1) / kBS;
+    h->nblocks = S.nbk * S.nbk * S.nbk;
+    const size_t n = (size_t)S.n, G = (size_t)n_grid * n_grid * n_grid;
+    const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)h->nblocks, n);   // for the smallest capacity (64)
+    int rc = 0;
+    rc |= dev_alloc(h, &S.gin, G, true); rc |= dev_alloc(h, &S.gout, G, true);
+    rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks, true); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks, true);
+    rc |= dev_alloc(h, &h->items, max_items, true);
+    rc |= dev_alloc(h, &h->active_list, (size_t)h->nblocks, true);
+    rc |= dev_alloc(h, &h->nbr_table, (size_t)h->nblocks * 28, true);
+    rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks, true); rc |= dev_alloc(h, &h->blk_flags, (size_t)h->nblocks, true);
+    rc |= dev_alloc(h, &h->part, max_items * kTN, true);
+    h->n_items = 0; h->n_active = 0;
+    h->needs_sort = true; h->xref_valid = false;
+    h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false;
+    if (h->resort_auto) h->resort_interval = 4;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1423,27 +1464,17 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     PX_REQUIRE(out && n_particles > 0 && n_grid >= 4 && grid_lim > 0, "pixie_mpm_create: bad arguments");
     pixie_mpm* h = new pixie_mpm();
     MpmPtrs& S = h->S;
-    S.n = n_particles; S.ng = n_grid;
-    h->grid_lim = grid_lim;
-    S.dx = (float)(grid_lim / n_grid);              // mpm_solver_warp.py:62-66
-    S.inv_dx = (float)((double)n_grid / grid_lim);
-    const size_t n = (size_t)n_particles, G = (size_t)n_grid * n_grid * n_grid;
+    S.n = n_particles;
+    const size_t n = (size_t)n_particles;
     int rc = 0;
-    S.nbk = (n_grid + kBS - 1) / kBS;
-    h->nblocks = S.nbk * S.nbk * S.nbk;
-    const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)h->nblocks, n);   // for the smallest capacity (64)
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
-    rc |= dev_alloc(h, &S.gin, G); rc |= dev_alloc(h, &S.gout, G);
     rc |= dev_alloc(h, &S.oob, 3);
     rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n); rc |= dev_alloc(h, &h->order2, n);
-    rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks);
-    rc |= dev_alloc(h, &h->items, max_items); rc |= dev_alloc(h, &h->d_n_items, 4);
-    rc |= dev_alloc(h, &h->active_list, (size_t)h->nblocks);
-    rc |= dev_alloc(h, &h->nbr_table, (size_t)h->nblocks * 28);
-    rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks); rc |= dev_alloc(h, &h->blk_flags, (size_t)h->nblocks); rc |= dev_alloc(h, &h->part, max_items * kTN);
+    rc |= dev_alloc(h, &h->d_n_items, 4);
+    rc |= alloc_grid(h, n_grid, grid_lim);
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
-    if (hipHostMalloc((void**)&h->h_n_items, 8 * sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
+    if (hipHostMalloc((void**)&h->h_n_items, 12 * sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
     bind_rows(h);
     hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.perm, n_particles);
     hipLaunchKernelGGL(identity_F_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.Ft, n_particles);  // :272-277
@@ -1460,11 +1491,21 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
 int pixie_mpm_destroy(pixie_mpm* h) {
     if (!h) return 0;
     for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->grid_allocs) (void)hipFree(p);
     for (int* m : h->masks) (void)hipFree(m);
     if (h->h_n_items) (void)hipHostFree(h->h_n_items);
     for (auto& e : h->ev_particle) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : h->ev_grid) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
+    return 0;
+}
+
+int pixie_mpm_regrid(pixie_mpm* h, int n_grid, double grid_lim, void* stream) {
+    PX_REQUIRE(h && n_grid >= 4 && grid_lim > 0, "pixie_mpm_regrid: bad arguments");
+    PX_REQUIRE(!h->dirty_grid, "pixie_mpm_regrid: a phase-API P2G is pending");
+    PX_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));   // nothing may still be reading the old grid
+    if (alloc_grid(h, n_grid, grid_lim)) return 1;
+    bind_rows(h);
     return 0;
 }
 
@@ -1586,6 +1627,7 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
+    else if (k == "lost_particles_seen") *value = (double)h->lost_seen;   // as of the last re-binning; does not synchronise
     else if (k == "dropped_particles") {  // slow-path particles that had left every active block; synchronises the device
         unsigned long long v = 0;
         PX_CHECK_HIP(hipMemcpy(&v, h->S.oob + 2, sizeof v, hipMemcpyDeviceToHost));

@@ -289,11 +289,8 @@ static int launch_attention(const float* qkv, float* out, int T, hipStream_t st)
     const size_t qs = (size_t)C * ATT_BQ * sizeof(float);
     const size_t lds = merge > qs ? merge : qs;
     auto kern = attention_kernel<C>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per launch: the attribute belongs to the (function, device) pair and a process may drive several devices
+    PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((T + ATT_BQ - 1) / ATT_BQ), dim3(ATT_WAVES * 64), lds, st, qkv, out, T);
     PX_CHECK_HIP(hipGetLastError());
     return 0;

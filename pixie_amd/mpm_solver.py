@@ -283,13 +283,11 @@ class MPM_Simulator_WARP:
             self._update_mass()
 
     def _regrid(self, n_grid, grid_lim):
-        """set_parameters_dict may change n_grid / grid_lim after the particles were loaded (:315-342)."""
-        saved = {nm: self.get_field(nm) for nm in _PERSISTENT}
-        t = self.time
-        self.initialize(self.n_particles, n_grid, grid_lim, device=str(self.device))
-        for nm, val in saved.items():
-            self.set_field(nm, val)
-        self.time = t
+        """set_parameters_dict may change n_grid / grid_lim after the particles were loaded (:315-342): like the
+        reference, only the grid arrays are re-made and dx / inv_dx recomputed; particle fields, model scalars,
+        boundary conditions, particle modifiers and the time survive (pixie_mpm_regrid, in place)."""
+        check(_lib.load().pixie_mpm_regrid(self._h, int(n_grid), float(grid_lim), self._stream), "pixie_mpm_regrid")
+        self.n_grid, self.grid_lim = int(n_grid), float(grid_lim)
 
     def set_per_particle(self, E=None, nu=None, density=None, material=None, yield_stress=None):
         """Per-particle material assignment -- what material_field.py:343-363 does with N
@@ -319,10 +317,21 @@ class MPM_Simulator_WARP:
     def p2g2p(self, step, dt, device="cuda:0"):
         """:514-637 -- one substep; asynchronous on the current stream."""
         check(_lib.load().pixie_mpm_step(self._h, float(dt), 1, self._stream), "pixie_mpm_step")
+        self._warn_if_particles_lost()
 
     def run(self, dt, n_substeps):
         """n substeps of p2g2p in one call (fused G2P->P2G launches, no host synchronisation)."""
         check(_lib.load().pixie_mpm_step(self._h, float(dt), int(n_substeps), self._stream), "pixie_mpm_step")
+        self._warn_if_particles_lost()
+
+    def _warn_if_particles_lost(self):
+        """Mass leaving the simulation must not be silent: the count read back at the last re-binning (no sync)."""
+        lost = int(self._get_scalar("lost_particles_seen"))
+        if lost > getattr(self, "_lost_reported", 0):
+            import warnings
+            warnings.warn(f"MPM_Simulator_WARP: {lost} particle(s) left the {self.n_grid}^3 grid (or every active block) and "
+                          "were frozen / dropped from P2G; the reference writes out of bounds here", RuntimeWarning, stacklevel=3)
+            self._lost_reported = lost
 
     p2g2p_n = run
 
@@ -482,21 +491,20 @@ class MPM_Simulator_WARP:
                        translation_scale=translation_scale, start_time=start_time, end_time=end_time)
 
     def release_particles_sequentially(self, normal, start_position, end_position, num_layers, start_time, end_time):
-        """:1185-1210"""
-        num_layers = 50
-        point = [0, 0, 0]
-        size = [0, 0, 0]
-        axis = -1
+        """:1185-1210 -- pins the particles in `num_layers` nested slabs along the axis `normal` names and lets go of the
+        outermost slab first: slab k (k = 0 ... layers-1) spans (layers - k) * |start - end| / layers either side of
+        `end_position` and is held from `start_time` until (k + 1) * end_time / layers.  The reference overrides the
+        caller's `num_layers` with 50; kept."""
+        layers = 50
+        axis = next((i for i in (2, 1, 0) if normal[i] != 0), -1)   # the reference keeps the LAST non-zero component
+        centre = [1.0, 1.0, 1.0]
+        half = [1.0, 1.0, 1.0]
         for i in range(3):
-            if normal[i] == 0:
-                point[i] = 1
-                size[i] = 1
-            else:
-                axis = i
-                point[i] = end_position
-        half_length_portion = abs(start_position - end_position) / num_layers
-        end_time_portion = end_time / num_layers
-        for i in range(num_layers):
-            size[axis] = half_length_portion * (num_layers - i)
-            self.enforce_particle_velocity_translation(point=point, size=size, velocity=[0, 0, 0],
-                                                       start_time=start_time, end_time=end_time_portion * (i + 1))
+            if normal[i] != 0:
+                centre[i] = end_position
+                half[i] = 0.0
+        layer_thickness = abs(start_position - end_position) / layers
+        for k in range(layers):
+            half[axis] = layer_thickness * (layers - k)
+            self.enforce_particle_velocity_translation(point=list(centre), size=list(half), velocity=[0.0, 0.0, 0.0],
+                                                       start_time=start_time, end_time=(end_time / layers) * (k + 1))

@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -239,31 +240,43 @@ class UNetRunner:
         wmax, bmax = self._absmax(key)
         return math.sqrt(float(count)) * wmax + bmax + 1e-30
 
-    @staticmethod
-    def _new_slot(cache: dict, device) -> torch.Tensor:
+    _SLOT_POOL = 1024
+
+    @classmethod
+    def _new_slot(cls, cache: dict, device) -> torch.Tensor:
+        """One zeroed int32 device word (an atomicMax target for a tensor's |x|max).  Words come from pools of
+        _SLOT_POOL; a network deeper than one pool gets another pool, never an empty slice."""
         pool = cache.get("_slots")
-        if pool is None:
-            pool = cache["_slots"] = torch.zeros(1024, dtype=torch.int32, device=device)
+        if pool is None or cache["_next"] >= pool.numel():
+            pool = cache["_slots"] = torch.zeros(cls._SLOT_POOL, dtype=torch.int32, device=device)
             cache["_next"] = 0
         i = cache["_next"]
         cache["_next"] = i + 1
         return pool[i:i + 1]
+
+    @staticmethod
+    def _remember(cache: dict, t: torch.Tensor, sums, slot) -> None:
+        """Statistics of `t`, keyed by id(t) WITHOUT keeping t alive: the entry disappears with the tensor, so only
+        the tensors the graph still needs (the skip stack) stay resident during a forward pass."""
+        k = id(t)
+        cache[k] = (sums, slot)
+        weakref.finalize(t, cache.pop, k, None)
 
     def _stats(self, cache: dict, t: torch.Tensor):
         k = id(t)
         if k not in cache:
             if hasattr(self.ops, "channel_stats"):
                 slot = self._new_slot(cache, t.device)
-                cache[k] = (t, self.ops.channel_stats(t, slot), slot)  # keep t alive so id() stays unique
+                self._remember(cache, t, self.ops.channel_stats(t, slot), slot)
             else:
-                cache[k] = (t, self.ops.channel_sums(t), None)
+                self._remember(cache, t, self.ops.channel_sums(t), None)
         return cache[k]
 
     def _sums(self, cache: dict, t: torch.Tensor) -> torch.Tensor:
-        return self._stats(cache, t)[1]
+        return self._stats(cache, t)[0]
 
     def _amax(self, cache: dict, t: torch.Tensor) -> torch.Tensor:
-        return self._stats(cache, t)[2]
+        return self._stats(cache, t)[1]
 
     def _conv(self, cache: dict, parts: List[torch.Tensor], wkey: str, cout: int, ksize: int, *, stride: int = 1,
               upsample: bool = False, pro=None, affine_key: Optional[str] = None, act: int = ACT_NONE,
@@ -285,7 +298,7 @@ class UNetRunner:
             out, sums = ops.conv(parts, None, self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro, affine=affine,
                                  act=act, residual=residual, w16=self._w16(wkey), out_amax=slot, **kw)
             if sums is not None:
-                cache[id(out)] = (out, sums, slot)
+                self._remember(cache, out, sums, slot)
             return out
         return ops.conv(parts, None, self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro, affine=affine,
                         act=act, residual=residual, w16=self._w16(wkey), **kw)
