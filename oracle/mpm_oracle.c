@@ -32,7 +32,12 @@
 #endif
 typedef REAL real;
 
-#define R_(x) ((real)(x))
+/* Literals inside the reference's kernels are float32 constants, and every scalar that reaches a kernel -- struct members
+ * (dx, inv_dx, gravity, model scalars, collider / modifier parameters) and launch arguments (time, dt) -- is a float32.
+ * Both builds therefore see the SAME float32-rounded problem data; the float64 build only does the arithmetic (and keeps
+ * the particle / grid state) in double.  R_ = kernel literal, P_ = host value as the float32 the kernel receives. */
+#define R_(x) ((real)(float)(x))
+#define P_(x) ((real)(float)(x))
 
 static inline real r_log(real x) { return sizeof(real) == 4 ? (real)logf((float)x) : (real)log((double)x); }
 static inline real r_exp(real x) { return sizeof(real) == 4 ? (real)expf((float)x) : (real)exp((double)x); }
@@ -210,9 +215,9 @@ typedef struct {
 MPM *mpm_create(int n, int n_grid, double grid_lim) {
     MPM *s = (MPM *)calloc(1, sizeof(MPM));
     s->n = n; s->ng = n_grid;
-    s->grid_lim = (real)grid_lim;
-    s->dx = (real)(grid_lim / n_grid);           /* :62-66 */
-    s->inv_dx = (real)((double)n_grid / grid_lim);
+    s->grid_lim = P_(grid_lim);
+    s->dx = P_((grid_lim / n_grid));           /* :62-66 */
+    s->inv_dx = P_(((double)n_grid / grid_lim));
     size_t N = (size_t)n, G = (size_t)n_grid * n_grid * n_grid;
     s->x = calloc(3 * N, sizeof(real)); s->v = calloc(3 * N, sizeof(real));
     s->F = calloc(9 * N, sizeof(real)); s->F_trial = calloc(9 * N, sizeof(real));
@@ -225,7 +230,7 @@ MPM *mpm_create(int n, int n_grid, double grid_lim) {
     for (size_t p = 0; p < N; ++p) { s->F_trial[9 * p] = 1; s->F_trial[9 * p + 4] = 1; s->F_trial[9 * p + 8] = 1; } /* :272-277 */
     s->rpic_damping = 0; s->grid_v_damping_scale = R_(1.1); s->softening = R_(0.1); /* :79-92 */
     double sin_phi = sin(25.0 / 180.0 * 3.14159265);                                  /* :84-86 */
-    s->alpha = (real)(sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi));
+    s->alpha = P_((sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi)));
     s->time = 0.0;
     return s;
 }
@@ -258,19 +263,19 @@ void *mpm_field(MPM *s, const char *name, long *count, int *is_int) {
 }
 
 void mpm_set_scalar(MPM *s, const char *name, double val) {
-    if (!strcmp(name, "rpic_damping")) s->rpic_damping = (real)val;
-    else if (!strcmp(name, "grid_v_damping_scale")) s->grid_v_damping_scale = (real)val;
-    else if (!strcmp(name, "hardening")) s->hardening = (real)val;
-    else if (!strcmp(name, "xi")) s->xi = (real)val;
-    else if (!strcmp(name, "softening")) s->softening = (real)val;
-    else if (!strcmp(name, "plastic_viscosity")) s->plastic_viscosity = (real)val;
-    else if (!strcmp(name, "gx")) s->g[0] = (real)val;
-    else if (!strcmp(name, "gy")) s->g[1] = (real)val;
-    else if (!strcmp(name, "gz")) s->g[2] = (real)val;
+    if (!strcmp(name, "rpic_damping")) s->rpic_damping = P_(val);
+    else if (!strcmp(name, "grid_v_damping_scale")) s->grid_v_damping_scale = P_(val);
+    else if (!strcmp(name, "hardening")) s->hardening = P_(val);
+    else if (!strcmp(name, "xi")) s->xi = P_(val);
+    else if (!strcmp(name, "softening")) s->softening = P_(val);
+    else if (!strcmp(name, "plastic_viscosity")) s->plastic_viscosity = P_(val);
+    else if (!strcmp(name, "gx")) s->g[0] = P_(val);
+    else if (!strcmp(name, "gy")) s->g[1] = P_(val);
+    else if (!strcmp(name, "gz")) s->g[2] = P_(val);
     else if (!strcmp(name, "time")) s->time = val;
     else if (!strcmp(name, "friction_angle")) { /* mpm_solver_warp.py:390-393 */
         double sin_phi = sin(val / 180.0 * 3.14159265);
-        s->alpha = (real)(sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi));
+        s->alpha = P_((sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi)));
     }
 }
 double mpm_get_time(MPM *s) { return s->time; }
@@ -294,12 +299,12 @@ void mpm_compute_bulk(MPM *s) {
 /* apply_additional_params, mpm_utils.py:591-610 */
 void mpm_apply_additional_params(MPM *s, const double *point, const double *size, double E, double nu, double density, int material) {
     real pt[3], sz[3];
-    for (int d = 0; d < 3; ++d) { pt[d] = (real)point[d]; sz[d] = (real)size[d]; }
+    for (int d = 0; d < 3; ++d) { pt[d] = P_(point[d]); sz[d] = P_(size[d]); }
     for (int p = 0; p < s->n; ++p) {
         const real *pos = s->x + 3 * p;
         if (pos[0] > pt[0] - sz[0] && pos[0] < pt[0] + sz[0] && pos[1] > pt[1] - sz[1] && pos[1] < pt[1] + sz[1] &&
             pos[2] > pt[2] - sz[2] && pos[2] < pt[2] + sz[2]) {
-            s->E[p] = (real)E; s->nu[p] = (real)nu; s->density[p] = (real)density; s->material[p] = material;
+            s->E[p] = P_(E); s->nu[p] = P_(nu); s->density[p] = P_(density); s->material[p] = material;
         }
     }
 }
@@ -316,20 +321,20 @@ void mpm_add_surface_collider(MPM *s, const double *point, const double *normal,
     BC *b = new_bc(s);
     b->type = BC_SURFACE;
     double nn = 1.0 / sqrt(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2]);
-    for (int d = 0; d < 3; ++d) { b->point[d] = (real)point[d]; b->normal[d] = (real)(nn * normal[d]); }
-    b->surface_type = surface_type; b->friction = (real)friction; b->start_time = (real)t0; b->end_time = (real)t1;
+    for (int d = 0; d < 3; ++d) { b->point[d] = P_(point[d]); b->normal[d] = P_((nn * normal[d])); }
+    b->surface_type = surface_type; b->friction = P_(friction); b->start_time = P_(t0); b->end_time = P_(t1);
 }
 /* set_velocity_on_cuboid, mpm_solver_warp.py:853-872 */
 void mpm_set_velocity_on_cuboid(MPM *s, const double *point, const double *size, const double *vel, double t0, double t1, int reset) {
     BC *b = new_bc(s);
     b->type = BC_CUBOID;
-    for (int d = 0; d < 3; ++d) { b->point[d] = (real)point[d]; b->size[d] = (real)size[d]; b->velocity[d] = (real)vel[d]; }
-    b->start_time = (real)t0; b->end_time = (real)t1; b->reset = reset;
+    for (int d = 0; d < 3; ++d) { b->point[d] = P_(point[d]); b->size[d] = P_(size[d]); b->velocity[d] = P_(vel[d]); }
+    b->start_time = P_(t0); b->end_time = P_(t1); b->reset = reset;
 }
 /* add_bounding_box, mpm_solver_warp.py:910-915 */
 void mpm_add_bounding_box(MPM *s, double t0, double t1) {
     BC *b = new_bc(s);
-    b->type = BC_BBOX; b->start_time = (real)t0; b->end_time = (real)t1;
+    b->type = BC_BBOX; b->start_time = P_(t0); b->end_time = P_(t1);
 }
 
 static PMod *new_pmod(MPM *s) {
@@ -351,16 +356,16 @@ static void select_box(MPM *s, PMod *m) {
 void mpm_add_impulse(MPM *s, const double *force, double dt, const double *point, const double *size, int num_dt, double t0) {
     PMod *m = new_pmod(s);
     m->type = PM_IMPULSE;
-    m->start_time = (real)t0; m->end_time = (real)(t0 + dt * num_dt);
-    for (int d = 0; d < 3; ++d) { m->point[d] = (real)point[d]; m->size[d] = (real)size[d]; m->force[d] = (real)force[d]; }
+    m->start_time = P_(t0); m->end_time = P_((t0 + dt * num_dt));
+    for (int d = 0; d < 3; ++d) { m->point[d] = P_(point[d]); m->size[d] = P_(size[d]); m->force[d] = P_(force[d]); }
     select_box(s, m);
 }
 /* enforce_particle_velocity_translation, mpm_solver_warp.py:1031-1059 */
 void mpm_enforce_translation(MPM *s, const double *point, const double *size, const double *vel, double t0, double t1) {
     PMod *m = new_pmod(s);
     m->type = PM_TRANSLATION;
-    m->start_time = (real)t0; m->end_time = (real)t1;
-    for (int d = 0; d < 3; ++d) { m->point[d] = (real)point[d]; m->size[d] = (real)size[d]; m->velocity[d] = (real)vel[d]; }
+    m->start_time = P_(t0); m->end_time = P_(t1);
+    for (int d = 0; d < 3; ++d) { m->point[d] = P_(point[d]); m->size[d] = P_(size[d]); m->velocity[d] = P_(vel[d]); }
     select_box(s, m);
 }
 /* enforce_particle_velocity_rotation, mpm_solver_warp.py:1080-1135 + selection kernel mpm_utils.py:645-663.
@@ -369,10 +374,10 @@ void mpm_enforce_rotation(MPM *s, const double *point, const double *normal, con
                           double half_height, double radius, double rotation_scale, double translation_scale, double t0, double t1) {
     PMod *m = new_pmod(s);
     m->type = PM_ROTATION;
-    for (int d = 0; d < 3; ++d) { m->point[d] = (real)point[d]; m->normal[d] = (real)normal[d]; m->h1[d] = (real)h1[d]; m->h2[d] = (real)h2[d]; }
-    m->half_height = (real)half_height; m->radius = (real)radius;
-    m->rotation_scale = (real)rotation_scale; m->translation_scale = (real)translation_scale;
-    m->start_time = (real)t0; m->end_time = (real)t1;
+    for (int d = 0; d < 3; ++d) { m->point[d] = P_(point[d]); m->normal[d] = P_(normal[d]); m->h1[d] = P_(h1[d]); m->h2[d] = P_(h2[d]); }
+    m->half_height = P_(half_height); m->radius = P_(radius);
+    m->rotation_scale = P_(rotation_scale); m->translation_scale = P_(translation_scale);
+    m->start_time = P_(t0); m->end_time = P_(t1);
     for (int p = 0; p < s->n; ++p) {
         real o[3] = {s->x[3 * p] - m->point[0], s->x[3 * p + 1] - m->point[1], s->x[3 * p + 2] - m->point[2]};
         real dn = o[0] * m->normal[0] + o[1] * m->normal[1] + o[2] * m->normal[2];
@@ -502,6 +507,12 @@ static void rm_sand(MPM *s, int p, const real *Ft, real *Fout) {
 
 /* ------------------------------------------------------------------ kernels */
 /* zero_grid, mpm_utils.py:295-300 */
+/* Activity windows.  In the reference `time`, `start_time` and `end_time` reach the kernels as 32-bit floats whatever
+ * the host computes in, so the DECISION "is this modifier / collider active in this substep" is a float32 comparison.
+ * The float64 build keeps that decision in float32 (it is discrete: with time accumulated in double, 30 x 1e-4 is
+ * 0.00299999999999999 < 3e-3 whereas both round to the same float32) and only does the arithmetic in double. */
+#define WIN(t, a, b) ((float)(t) >= (float)(a) && (float)(t) < (float)(b))
+
 void mpm_zero_grid(MPM *s) {
     size_t G = (size_t)s->ng * s->ng * s->ng;
     memset(s->grid_m, 0, G * sizeof(real));
@@ -512,11 +523,11 @@ void mpm_zero_grid(MPM *s) {
 /* pre-P2G particle modifiers: apply_force mpm_solver_warp.py:1015-1027;
  * modify_particle_v_before_p2g (translation) :1061-1073; (rotation) :1137-1179 */
 void mpm_pre_p2g(MPM *s, double dt_d) {
-    real time = (real)s->time, dt = (real)dt_d;
+    real time = P_(s->time), dt = P_(dt_d);
     for (int k = 0; k < s->n_pmod; ++k) { /* impulses first (:529-535), in registration order */
         PMod *m = &s->pmods[k];
         if (m->type != PM_IMPULSE) continue;
-        if (time >= m->start_time && time < m->end_time)
+        if (WIN(time, m->start_time, m->end_time))
             for (int p = 0; p < s->n; ++p)
                 if (m->mask[p] == 1) {
                     real imp[3] = {m->force[0] / s->mass[p], m->force[1] / s->mass[p], m->force[2] / s->mass[p]};
@@ -526,7 +537,7 @@ void mpm_pre_p2g(MPM *s, double dt_d) {
     for (int k = 0; k < s->n_pmod; ++k) { /* then velocity modifiers (:537-547) */
         PMod *m = &s->pmods[k];
         if (m->type == PM_IMPULSE) continue;
-        if (!(time >= m->start_time && time < m->end_time)) continue;
+        if (!WIN(time, m->start_time, m->end_time)) continue;
         for (int p = 0; p < s->n; ++p) {
             if (m->mask[p] != 1) continue;
             if (m->type == PM_TRANSLATION) {
@@ -550,7 +561,7 @@ void mpm_pre_p2g(MPM *s, double dt_d) {
 
 /* compute_stress_from_F_trial, mpm_utils.py:467-526 */
 void mpm_compute_stress(MPM *s, double dt_d) {
-    real dt = (real)dt_d;
+    real dt = P_(dt_d);
     for (int p = 0; p < s->n; ++p) {
         int material = s->material[p];
         if (s->selection[p] != 0) continue;
@@ -600,7 +611,7 @@ static int stencil_inside(const MPM *s, const int *base) {
 
 /* p2g_apic_with_stress, mpm_utils.py:338-394 */
 void mpm_p2g(MPM *s, double dt_d) {
-    real dt = (real)dt_d;
+    real dt = P_(dt_d);
     for (int p = 0; p < s->n; ++p) {
         if (s->selection[p] != 0) continue;
         const real *stress = s->stress + 9 * p;
@@ -638,7 +649,7 @@ void mpm_p2g(MPM *s, double dt_d) {
 
 /* grid_normalization_and_gravity, mpm_utils.py:398-409 */
 void mpm_grid_update(MPM *s, double dt_d) {
-    real dt = (real)dt_d;
+    real dt = P_(dt_d);
     size_t G = (size_t)s->ng * s->ng * s->ng;
     for (size_t gi = 0; gi < G; ++gi)
         if (s->grid_m[gi] > R_(1e-15)) {
@@ -655,7 +666,7 @@ void mpm_grid_damping(MPM *s) {
 
 /* grid BC kernels + host modify: surface mpm_solver_warp.py:785-840; cuboid :874-905; bounding box :917-974 */
 void mpm_apply_bcs(MPM *s, double dt_d) {
-    real time = (real)s->time, dt = (real)dt_d;
+    real time = P_(s->time), dt = P_(dt_d);
     int ng = s->ng;
     for (int k = 0; k < s->n_bc; ++k) {
         BC *b = &s->bcs[k];
@@ -664,7 +675,7 @@ void mpm_apply_bcs(MPM *s, double dt_d) {
                 for (int iz = 0; iz < ng; ++iz) {
                     real *vo = s->grid_v_out + 3 * GI(s, ix, iy, iz);
                     if (b->type == BC_SURFACE) {
-                        if (time >= b->start_time && time < b->end_time) {
+                        if (WIN(time, b->start_time, b->end_time)) {
                             real off[3] = {(real)ix * s->dx - b->point[0], (real)iy * s->dx - b->point[1], (real)iz * s->dx - b->point[2]};
                             real dp = off[0] * b->normal[0] + off[1] * b->normal[1] + off[2] * b->normal[2];
                             if (dp < R_(0.0)) {
@@ -684,17 +695,17 @@ void mpm_apply_bcs(MPM *s, double dt_d) {
                             }
                         }
                     } else if (b->type == BC_CUBOID) {
-                        if (time >= b->start_time && time < b->end_time) {
+                        if (WIN(time, b->start_time, b->end_time)) {
                             real off[3] = {(real)ix * s->dx - b->point[0], (real)iy * s->dx - b->point[1], (real)iz * s->dx - b->point[2]};
                             if (r_abs(off[0]) < b->size[0] && r_abs(off[1]) < b->size[1] && r_abs(off[2]) < b->size[2]) {
                                 vo[0] = b->velocity[0]; vo[1] = b->velocity[1]; vo[2] = b->velocity[2];
                             }
                         } else if (b->reset == 1) {
-                            if (time < b->end_time + R_(15.0) * dt) { vo[0] = vo[1] = vo[2] = 0; }
+                            if ((float)time < (float)b->end_time + 15.0f * (float)dt) { vo[0] = vo[1] = vo[2] = 0; }
                         }
                     } else if (b->type == BC_BBOX) {
                         int padding = 3;
-                        if (time >= b->start_time && time < b->end_time) {
+                        if (WIN(time, b->start_time, b->end_time)) {
                             if (ix < padding && vo[0] < 0) vo[0] = 0;
                             if (ix >= ng - padding && vo[0] > 0) vo[0] = 0;
                             if (iy < padding && vo[1] < 0) vo[1] = 0;
@@ -705,15 +716,15 @@ void mpm_apply_bcs(MPM *s, double dt_d) {
                     }
                 }
         if (b->type == BC_CUBOID) { /* host `modify`, :899-905: python-float arithmetic, stored back as f32 vec3 */
-            if (s->time >= (double)b->start_time && s->time < (double)b->end_time)
-                for (int d = 0; d < 3; ++d) b->point[d] = (real)((double)b->point[d] + dt_d * (double)b->velocity[d]);
+            if (s->time >= (double)(float)b->start_time && s->time < (double)(float)b->end_time)   /* the struct members are float32 */
+                for (int d = 0; d < 3; ++d) b->point[d] = P_((double)b->point[d] + dt_d * (double)b->velocity[d]);
         }
     }
 }
 
 /* g2p, mpm_utils.py:412-463 (update_cov_with_F is always False in the reference flows) */
 void mpm_g2p(MPM *s, double dt_d) {
-    real dt = (real)dt_d;
+    real dt = P_(dt_d);
     for (int p = 0; p < s->n; ++p) {
         if (s->selection[p] != 0) continue;
         int base[3]; real fx[3], w[3][3], dw[3][3];

@@ -153,7 +153,7 @@ class OracleMPM:
         self.field("material")[:] = self.material
         for key, fld in (("E", "E"), ("nu", "nu"), ("bulk_modulus", "bulk"), ("yield_stress", "yield_stress")):
             if key in kwargs:
-                self.field(fld)[:] = kwargs[key]
+                self.field(fld)[:] = np.float32(kwargs[key])   # the reference fills a float32 array (warp_utils.py:222-230)
         for key in ("hardening", "xi", "friction_angle", "rpic_damping", "plastic_viscosity", "softening", "grid_v_damping_scale"):
             if key in kwargs:
                 self._lib.mpm_set_scalar(self._h, key.encode(), float(kwargs[key]))
@@ -161,7 +161,7 @@ class OracleMPM:
             for ax, nm in enumerate(("gx", "gy", "gz")):
                 self._lib.mpm_set_scalar(self._h, nm.encode(), float(kwargs["g"][ax]))
         if "density" in kwargs:
-            self.field("density")[:] = kwargs["density"]
+            self.field("density")[:] = np.float32(kwargs["density"])
             self._lib.mpm_update_mass(self._h)
         if "additional_material_params" in kwargs:
             for prm in kwargs["additional_material_params"]:

@@ -11,8 +11,10 @@ A full 128^3 output pair is 88 MiB, so the fixture keeps, per head:
   l2       per-channel L2 norm of the FULL output (float64): catches errors anywhere in the volume
   sum      per-channel sum of the full output (float64)
   hist     (seg only) histogram of argmax over the full volume: class-decision parity at scale
-  f64_*    the same quantities from a float64 run of the reference modules (optional, --f64): the reference's own
-           fp32 rounding error, i.e. the noise floor any fp32 implementation is entitled to
+  f64_*    the same quantities in float64 (optional, --f64), from oracle/unet_oracle.py -- the restatement that is pinned
+           bit-for-bit to the reference modules in fp32; the reference itself hard-codes float32 in inner_dtype and
+           GroupNorm32.  reference-f32 vs f64 is the reference's own rounding error: the noise floor any fp32
+           implementation is entitled to
 """
 import os
 import sys
@@ -25,6 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from make_unet_golden import HEADS, reference_model  # noqa: E402
 
+from oracle import unet_oracle  # noqa: E402
 from pixie_amd.synthetic import feature_grid  # noqa: E402
 from pixie_amd.unet_plan import UNetConfig, synthetic_state_dict  # noqa: E402
 
@@ -66,13 +69,9 @@ def run(D: int, with_f64: bool):
         for k, v in digest(out, head == "seg").items():
             res[f"{head}_{k}"] = v
         if with_f64:
-            # the reference pins the torso to float32 (`inner_dtype`, diffusion_network.py:891-897); the float64 twin
-            # overrides that one property and nothing else
-            type(model.unet).inner_dtype = property(lambda self: torch.float64)
-            model = model.double()
             t0 = time.time()
             with torch.no_grad():
-                out64 = model(torch.from_numpy(feat).double()).numpy()
+                out64 = unet_oracle.unet_forward(synthetic_state_dict(cfg, off), cfg, feat, dtype=torch.float64).numpy()
             print(f"{D}^3 {head} f64: {time.time() - t0:.1f} s; reference f32 vs f64 rel-L2 "
                   f"{np.linalg.norm(out - out64) / np.linalg.norm(out64):.3e}", flush=True)
             for k, v in digest(out64, head == "seg", "f64_").items():
@@ -81,7 +80,6 @@ def run(D: int, with_f64: bool):
             if head == "seg":
                 res["seg_ref_f32_vs_f64_argmax_agreement"] = float((out[0].argmax(0) == out64[0].argmax(0)).mean())
             del out64
-            type(model.unet).inner_dtype = property(lambda self: torch.float32)
         del model, out
     np.savez_compressed(os.path.join(HERE, f"unet_full{D}.npz"), **res)
     print("wrote", f"unet_full{D}.npz", flush=True)
