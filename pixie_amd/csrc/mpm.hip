@@ -495,11 +495,10 @@ constexpr int kMpmTraceItems = 32768;
 __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
 #define PX_MPM_STAMP(i) do { if (DO_G2P && DO_P2G && sp.trace && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
-#ifndef PX_MPM_WAVES
-#define PX_MPM_WAVES 3
-#endif
-template <bool DO_G2P, bool DO_P2G>
-__global__ __launch_bounds__(kWG, PX_MPM_WAVES) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
+// OCC = waves per SIMD the register allocation is held to (launch_bounds): 3 -> 168 VGPRs, no spills; 4 -> 128 VGPRs
+// (52 spilled dwords, mostly on the svd3 / slow paths); chosen at run time (set_scalar "occupancy"), same arithmetic.
+template <bool DO_G2P, bool DO_P2G, int OCC>
+__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
     __shared__ unsigned long long ta[4][kTN];  // (m*v.xyz, m) of this work item as scaled 64-bit integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
@@ -1167,6 +1166,7 @@ struct pixie_mpm {
     unsigned long long slow_at_rebin = 0;
     unsigned long long lost_seen = 0;        // oob[0] + oob[2] as read back at the last re-binning
     int2* blk_items = nullptr;               // per block: (first work item, item count)
+    int occupancy = 3;                       // register-allocation target of the fused kernel (waves per SIMD): 3, 4 or 5
     int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
     bool pmods_were_active = false;
@@ -1349,18 +1349,20 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        hipLaunchKernelGGL((mpm_block_kernel<true, true>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+        if (h->occupancy >= 5) hipLaunchKernelGGL((mpm_block_kernel<true, true, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+        else if (h->occupancy == 4) hipLaunchKernelGGL((mpm_block_kernel<true, true, 4>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+        else hipLaunchKernelGGL((mpm_block_kernel<true, true, 3>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
     } else {
         if (g2p) {
             PModSet none{};
-            hipLaunchKernelGGL((mpm_block_kernel<true, false>), grid, dim3(h->item_cap), 0, st, h->S, sp, none);
+            hipLaunchKernelGGL((mpm_block_kernel<true, false, 3>), grid, dim3(h->item_cap), 0, st, h->S, sp, none);
         }
         if (p2g) {
             if (!fused_mods) {
                 for (const PModDev& m : ordered)
                     hipLaunchKernelGGL(pmod_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, m);
             }
-            hipLaunchKernelGGL((mpm_block_kernel<false, true>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+            hipLaunchKernelGGL((mpm_block_kernel<false, true, 3>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
         }
     }
     if (e0) {
@@ -1609,6 +1611,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
     else if (k == "trace") h->trace = (int)value;
+    else if (k == "occupancy") { PX_REQUIRE(value == 3 || value == 4 || value == 5, "occupancy must be 3, 4 or 5 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);

@@ -200,8 +200,8 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
 // the caller then takes the svd3 route.
 PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
     R = F;
-    float last = 1.0f;
     float det = 1.0f;
+    bool settled = false;   // this lane's iterate moved by < 2e-6 in its last step: frozen from then on
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -233,11 +233,17 @@ PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
         for (int i = 0; i < 9; ++i) {
             const float r = a * R.m[i] + b * cof.m[i];
             delta = fmaxf(delta, fabsf(r - R.m[i]));
-            R.m[i] = r;
+            if (!settled) R.m[i] = r;
         }
-        last = delta;
+        // A lane stops at ITS OWN convergence (the Newton step that moved it by < 2e-6 leaves an error of ~1e-12), so
+        // its result does not depend on which other particles share its wave; the wave leaves the loop once every
+        // lane has settled -- typically after 3 of the 6 steps for the strains of a stable simulation.
+        if (!settled && delta < 2e-6f) settled = true;   // NaN (singular F) never settles
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (it >= 2 && __all(settled)) break;
+#endif
     }
-    return det > 0.0f && last < 2e-6f;  // NaN (singular F) compares false
+    return det > 0.0f && settled;
 }
 
 // ---------------------------------------------------------------- constitutive models

@@ -160,26 +160,123 @@ def test_single_step_api_equals_batched(hip_device):
     for i in range(20):
         a.p2g2p(i, sc["dt"])
     b.run(sc["dt"], 20)
+    # Both are deterministic (fixed-point tile sums, fixed-order grid gather), but not the same arithmetic: the fused
+    # kernel keeps v, C and F_trial in registers between G2P and the next P2G, the single-step API stores and reloads
+    # them through the caller-visible arrays in between (bit-identical values) and runs the stress on its own launch
+    # with a different instruction schedule (FMA contraction across the fused boundary differs).  Each path IS
+    # reproducible: two runs of the same path must agree bit for bit.
     assert rel_l2(get(a, "x"), get(b, "x")) < 1e-6
     assert rel_l2(get(a, "v"), get(b, "v")) < 1e-4
+    c = make_hip(sc)
+    c.run(sc["dt"], 20)
+    for f in ("x", "v", "C", "F_trial"):
+        assert np.array_equal(get(b, f), get(c, f)), f"run() is not bit-reproducible in {f}"
 
 
-@pytest.mark.parametrize("material,extra", [("sand", dict(friction_angle=30.0)), ("metal", dict(yield_stress=3e3, hardening=1, xi=0.05)),
-                                            ("snow", dict(yield_stress=3e3, hardening=0, softening=0.1))])
-def test_plastic_materials_rollout(hip_device, material, extra):
-    sc = mpm_ball_scene(8000, seed=6, scenario="ball")
-    sc["params"] = dict(material=material, g=[0.0, 0.0, -9.8], E=1e5, nu=0.3, density=1000.0, **extra)
-    h, o = make_hip(sc, per_particle=False), make_oracle(sc, "f64", per_particle=False)
+PLASTIC = [
+    # (name, material id, set_parameters_dict entries) -- ids 3 (visco-plastic) and 6 (water EOS) have no entry in the
+    # reference's name map (mpm_solver_warp.py:20-26 excludes "visplas"/"fluid"; "stationary" is id 6 with bulk = 0), so
+    # they are assigned per particle, as material_field.py:343-363 does
+    ("sand", 2, dict(material="sand", friction_angle=30.0)),
+    ("metal", 1, dict(material="metal", yield_stress=3e3, hardening=1, xi=0.05)),
+    ("snow", 5, dict(material="snow", yield_stress=3e3, hardening=0, softening=0.1)),
+    ("visplas", 3, dict(material="jelly", yield_stress=2e3, plastic_viscosity=10.0)),
+    ("water", 6, dict(material="stationary")),
+]
+
+
+@pytest.mark.parametrize("name,mid,extra", PLASTIC, ids=[m[0] for m in PLASTIC])
+def test_plastic_materials_rollout(hip_device, name, mid, extra):
+    """Every constitutive branch of compute_stress_from_F_trial (mpm_utils.py:467-526) on the device, 60 substeps from a
+    deformed state, against the float64 oracle.  Tolerances: x, F at the north-star 1e-4; every quantity additionally
+    gets k = 4 times the distance of the float32 ORACLE from the float64 oracle (the same restatement run in the
+    reference's own precision), because the return mappings are discontinuous maps of F (yield / no yield, the sand
+    cone's three cases): a particle sitting within rounding distance of the yield surface takes the other branch in
+    float32, which is a property of the reference's arithmetic, not of this implementation.  The measured numbers are
+    printed; where the float32 oracle's drift is below 2.5e-5 the bar is just 1e-4."""
+    n = 8000
+    sc = mpm_ball_scene(n, seed=6, scenario="ball")
+    sc["params"] = dict(g=[0.0, 0.0, -9.8], E=1e5, nu=0.3, density=1000.0, **extra)
+    h = make_hip(sc, per_particle=False)
+    o, o32 = make_oracle(sc, "f64", per_particle=False), make_oracle(sc, "f32", per_particle=False)
+    for s in (h, o, o32):
+        s.set_per_particle(material=np.full(n, mid, np.int32))
+        if mid == 6:
+            s.finalize_mu_lam_bulk()
     # start deformed so the return mappings are exercised from step 1
     rng = np.random.default_rng(1)
-    Ft = (np.eye(3) + 0.05 * rng.normal(size=(8000, 3, 3))).astype(np.float32)
-    h.set_field("F_trial", Ft.reshape(8000, 9)); o.field("F_trial")[:] = Ft
-    h.run(sc["dt"], 60); o.run(sc["dt"], 60)
-    assert rel_l2(get(h, "x"), o.field("x")) < 1e-4
-    assert rel_l2(get(h, "F").reshape(-1, 3, 3), o.field("F")) < 2e-3
-    assert rel_l2(get(h, "v"), o.field("v")) < 2e-2
-    if material != "sand":
-        assert rel_l2(get(h, "yield_stress"), o.field("yield_stress")) < 1e-3
+    Ft = (np.eye(3) + 0.05 * rng.normal(size=(n, 3, 3))).astype(np.float32)
+    h.set_field("F_trial", Ft.reshape(n, 9)); o.field("F_trial")[:] = Ft; o32.field("F_trial")[:] = Ft
+    h.run(sc["dt"], 60); o.run(sc["dt"], 60); o32.run(sc["dt"], 60)
+    v_rms = float(np.linalg.norm(o.field("v")) / np.sqrt(n))
+    report = []
+    for f, shape in (("x", (n, 3)), ("F", (n, 3, 3)), ("v", (n, 3)), ("yield_stress", (n,))):
+        if f == "yield_stress" and mid not in (1, 3, 5):
+            continue
+        ref = o.field(f).astype(np.float64)
+        scale = max(np.linalg.norm(ref), (v_rms * np.sqrt(n)) if f == "v" else 0.0, 1e-300)
+        err = float(np.linalg.norm(get(h, f).reshape(shape).astype(np.float64) - ref) / scale)
+        drift = float(np.linalg.norm(o32.field(f).astype(np.float64) - ref) / scale)
+        report.append(f"{f}: hip {err:.2e} / f32-oracle {drift:.2e}")
+        assert err < max(1e-4, 4 * drift), (name, f, err, drift)
+    print(f"{name}: " + "; ".join(report))
+    assert float(np.abs(get(h, "stress")).max()) > 0
+    if mid != 6:
+        assert rel_l2(get(h, "F"), get(h, "F_trial")) > 1e-6   # the return mapping moved F
+    assert h.out_of_bounds == 0
+
+
+def test_rollout_parity_config3(hip_device):
+    """The north-star MPM configuration (BASELINE configs[2]: 100 000 particles, n_grid 50, the tree scenario -- the scene
+    bench.py times) for 1 000 substeps against the float64 C oracle.  The oracle needs ~4 min per precision at this size,
+    so its trajectory is a committed fixture (tests/golden/make_mpm_golden.py; tests/test_mpm_oracle.py re-runs its first
+    checkpoint live): every 16th particle's x, v, C, F_trial at substeps 20 / 100 / 500 / 1000, whole-population norms,
+    momentum and centre of mass, and the float32 oracle's own drift from the float64 one.
+    Bar: x and F_trial <= 1e-4 outright; the displacement, v and C <= max(1e-4, 4 x the float32 oracle's drift), v and C
+    measured on the scale of the velocity field as in test_rollout_parity."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpm_config3.npz"))
+    n, stride = int(g["n"]), int(g["stride"])
+    sc = mpm_ball_scene(n, seed=int(g["seed"]))
+    assert sc["n_grid"] == int(g["n_grid"]) and sc["dt"] == float(g["dt"])
+    h = make_hip(sc)
+    x0 = sc["x"].astype(np.float64)
+    mass = get(h, "mass").astype(np.float64)
+    inv_dx = sc["n_grid"] / sc["grid_lim"]
+    done = 0
+    for cp in [int(c) for c in g["checkpoints"]]:
+        h.run(sc["dt"], cp - done)
+        done = cp
+        x, v, C, F = (get(h, f).astype(np.float64) for f in ("x", "v", "C", "F_trial"))
+        C, F = C.reshape(-1, 3, 3), F.reshape(-1, 3, 3)
+        d_x, d_disp, d_v, d_C, d_F = (float(t) for t in g[f"drift_{cp}"])
+        m = n // stride + (1 if n % stride else 0)
+        ns = np.sqrt(m)
+        v_rms = float(np.linalg.norm(g[f"v_{cp}"]) / ns)
+        c_scale = max(v_rms * inv_dx, float(np.linalg.norm(g[f"C_{cp}"]) / ns))
+        e_x = rel_l2(x[::stride], g[f"x_{cp}"])
+        e_F = rel_l2(F[::stride], g[f"F_trial_{cp}"])
+        e_disp = rel_l2((x - x0)[::stride], g[f"x_{cp}"] - x0[::stride])
+        e_v = float(np.linalg.norm(v[::stride] - g[f"v_{cp}"]) / ns) / v_rms
+        e_C = float(np.linalg.norm(C[::stride] - g[f"C_{cp}"]) / ns) / c_scale
+        # the float32 oracle's drift on the same scales (the fixture stores norm-relative numbers over all particles)
+        dv = d_v * float(g[f"norms_{cp}"][1]) / np.sqrt(n) / v_rms
+        dC = d_C * float(g[f"norms_{cp}"][2]) / np.sqrt(n) / c_scale
+        norms = np.array([np.linalg.norm(x - x0), np.linalg.norm(v), np.linalg.norm(C), np.linalg.norm(F - np.eye(3))])
+        e_norm = np.abs(norms / g[f"norms_{cp}"] - 1.0)
+        p = (mass[:, None] * v).sum(0)
+        e_p = float(np.linalg.norm(p - g[f"momentum_{cp}"]) / (np.linalg.norm(mass) * v_rms * np.sqrt(n) / np.sqrt(n)))
+        e_com = float(np.abs((mass[:, None] * x).sum(0) / mass.sum() - g[f"com_{cp}"]).max())
+        print(f"config 3 @ substep {cp}: x {e_x:.2e}, F_trial {e_F:.2e}, displacement {e_disp:.2e} (f32 oracle {d_disp:.2e}), "
+              f"v {e_v:.2e} (f32 oracle {dv:.2e}), C {e_C:.2e} (f32 oracle {dC:.2e}); whole-population norms off by "
+              f"{e_norm.max():.2e}, momentum {e_p:.2e}, centre of mass {e_com:.2e}")
+        assert np.isfinite(x).all() and np.isfinite(v).all()
+        assert e_x < 1e-4 and e_F < 1e-4
+        assert e_disp < max(1e-4, 4 * d_disp)
+        assert e_v < max(1e-4, 4 * dv) and e_C < max(1e-4, 4 * dC)
+        assert e_norm[0] < max(1e-4, 4 * d_disp) and e_norm[3] < 1e-3 and e_com < 1e-6
+    assert h.out_of_bounds == 0 and int(g["oob"][0]) == 0
+    assert abs(h.time - 1000 * sc["dt"]) < 1e-9
 
 
 def test_boundary_conditions_and_modifiers(hip_device):

@@ -179,3 +179,22 @@ def test_device_stencil_matches_oracle():
     gp = x * inv_dx
     assert np.array_equal(base, (gp - np.float32(0.5)).astype(np.int32))
     assert np.abs(w.sum(2) - 1).max() < 1e-6 and np.abs(dw.sum(2)).max() < 1e-6
+
+
+def test_config3_fixture_is_this_oracle():
+    """tests/golden/mpm_config3.npz (the 100 000-particle, 1 000-substep trajectory the GPU test compares the HIP solver
+    with) was produced by oracle/mpm_oracle.c: re-running its first checkpoint (20 substeps, ~6 s) with the oracle in
+    the tree must reproduce it to the last bit (serial C, same compiler flags), so the fixture cannot drift from the
+    oracle source unnoticed."""
+    import os
+    from pixie_amd.synthetic import apply_scene, mpm_ball_scene
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpm_config3.npz"))
+    n, stride, cp = int(g["n"]), int(g["stride"]), int(g["checkpoints"][0])
+    sc = mpm_ball_scene(n, seed=int(g["seed"]))
+    o = OracleMPM(n, sc["n_grid"], sc["grid_lim"], "f64")
+    o.load_initial_data(sc["x"], sc["vol"], sc["cov"])
+    apply_scene(o, sc)
+    o.run(sc["dt"], cp)
+    for f in ("x", "v", "F_trial", "C"):
+        got, want = np.asarray(o.field(f))[::stride], g[f"{f}_{cp}"]
+        assert np.array_equal(got, want) or float(np.abs(got - want).max()) <= 1e-13 * max(float(np.abs(want).max()), 1e-300), f
