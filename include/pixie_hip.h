@@ -238,6 +238,11 @@ int pixie_voxel_grid_to_ncdhw(const void* d_feat_dhwc_f16, int d, int h, int w, 
 int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial,
                               float* d_combined, int32_t* d_argmax /* may be NULL */, void* stream);
 
+/* save_predictions given class ids (WG/trainer/inference_combined.py:173-199): combined[0:3] = cont_pred,
+ * combined[3 + k] = (seg_pred == k) for k < num_classes (an id outside [0, num_classes) leaves every class channel 0). */
+int pixie_combine_class_ids(const int32_t* d_seg_pred, int num_classes, const float* d_cont, int64_t spatial, float* d_combined,
+                            void* stream);
+
 /* ======================================================================================
  * (C) Field -> particle transfer between the two halves: replaces the PLY round trip
  *     pixie/voxel/map_pred_to_coords.py:41-75,192-252 (unscale_prediction + masked voxel point list) and
@@ -263,6 +268,22 @@ int pixie_field_to_particles(const pixie_field_desc* field, const float* d_pos, 
                              int weighted, int default_material, int default_part_label, float* d_density, float* d_E,
                              float* d_nu, int32_t* d_material, int32_t* d_part_label, float* d_conf, float* d_nearest,
                              void* d_scratch, void* stream);
+
+/* unscale_prediction (pixie/voxel/map_pred_to_coords.py:41-75): d_out[(channels, spatial)] = d_pred with channels 0..2
+ * clipped to [-1, 1] and mapped back to physical units -- density and E through 10^(log-range), nu linearly, with the
+ * ranges of normalization_stats/normalization_ranges.yaml; the class channels (3..) are copied.  float32 arithmetic,
+ * as numpy does on the float32 array.  d_out may alias d_pred. */
+int pixie_unscale_prediction(const float* d_pred, int channels, int64_t spatial, double density_min, double density_max,
+                             double E_min, double E_max, double nu_min, double nu_max, float* d_out, void* stream);
+/* The masked voxel point list map_pred_to_ply writes to its PLY (map_pred_to_coords.py:192-252): for every voxel with
+ * mask > 0, in C order of the grid, its coordinates (the float32 lattice axes of `field`), un-scaled density / E / nu,
+ * material id (argmax of the class channels, first maximum; a single class channel is the id itself, :122-126) and
+ * confidence (the winning class score; 1 for a single channel).  *d_count (device int64) receives the number of points;
+ * at most `capacity` records are written (call with capacity 0 to only count).  d_scratch needs
+ * pixie_field_points_scratch_bytes(field) bytes.  Stable compaction, three launches, asynchronous on `stream`. */
+int64_t pixie_field_points_scratch_bytes(const pixie_field_desc* field);
+int pixie_field_points(const pixie_field_desc* field, int64_t capacity, float* d_xyz /* [n][3] */, float* d_density, float* d_E,
+                       float* d_nu, int32_t* d_material, float* d_conf, int64_t* d_count, void* d_scratch, void* stream);
 
 #ifdef __cplusplus
 }

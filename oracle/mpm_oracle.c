@@ -163,7 +163,101 @@ static void svd3_f64(const double *A, double *U, double *S, double *V) {
     if (dV < 0) { V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8]; S[2] = -S[2]; }
 }
 
+/* The same algorithm carried out in float: what the float32 build uses, so that its distance from the float64 build
+ * includes the rounding noise of a single-precision SVD (Warp's wp.svd3 runs in float32 on float32 matrices).  An
+ * earlier version computed the float32 build's SVD in double and rounded the result, which made the "float32 oracle"
+ * 2-3x more accurate in the plastic stresses than any float32 implementation of the reference can be. */
+static void svd3_f32(const float *A, float *U, float *S, float *V) {
+    float B[9];
+    memcpy(B, A, sizeof B);
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        float off = 0.0f;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                float al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; ++i) {
+                    al += B[3 * i + p] * B[3 * i + p];
+                    be += B[3 * i + q] * B[3 * i + q];
+                    ga += B[3 * i + p] * B[3 * i + q];
+                }
+                if (ga == 0.0f || fabsf(ga) <= 1e-37f) continue;
+                float lim = 1e-8f * sqrtf(al * be);
+                if (fabsf(ga) <= lim) continue;
+                off += fabsf(ga);
+                float zeta = (be - al) / (2.0f * ga);
+                float t = (zeta >= 0 ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+                float c = 1.0f / sqrtf(1.0f + t * t), s = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    float bp = B[3 * i + p], bq = B[3 * i + q];
+                    B[3 * i + p] = c * bp - s * bq;
+                    B[3 * i + q] = s * bp + c * bq;
+                    float vp = V[3 * i + p], vq = V[3 * i + q];
+                    V[3 * i + p] = c * vp - s * vq;
+                    V[3 * i + q] = s * vp + c * vq;
+                }
+            }
+        if (off == 0.0f) break;
+    }
+    float n[3];
+    for (int j = 0; j < 3; ++j)
+        n[j] = sqrtf(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+    /* sort columns by decreasing norm */
+    int idx[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (n[idx[b]] > n[idx[a]]) { int t = idx[a]; idx[a] = idx[b]; idx[b] = t; }
+    float Bs[9], Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        S[j] = n[idx[j]];
+        for (int i = 0; i < 3; ++i) { Bs[3 * i + j] = B[3 * i + idx[j]]; Vs[3 * i + j] = V[3 * i + idx[j]]; }
+    }
+    memcpy(V, Vs, sizeof Vs);
+    /* U columns = normalised B columns; rank-deficient columns completed by cross products */
+    for (int j = 0; j < 3; ++j) {
+        if (S[j] > 1e-37f && S[j] > 1e-6f * S[0]) {
+            for (int i = 0; i < 3; ++i) U[3 * i + j] = Bs[3 * i + j] / S[j];
+        } else {
+            S[j] = (S[j] > 1e-37f) ? S[j] : 0.0f;
+            for (int i = 0; i < 3; ++i) U[3 * i + j] = 0.0f;
+        }
+    }
+    /* complete basis if needed (only for singular A) */
+    float c0 = U[0] * U[0] + U[3] * U[3] + U[6] * U[6];
+    if (c0 < 0.5f) { U[0] = 1; U[3] = 0; U[6] = 0; }
+    float c1 = U[1] * U[1] + U[4] * U[4] + U[7] * U[7];
+    if (c1 < 0.5f) {
+        float a[3] = {U[0], U[3], U[6]};
+        float e[3] = {0, 0, 0};
+        int k = (fabsf(a[0]) <= fabsf(a[1]) && fabsf(a[0]) <= fabsf(a[2])) ? 0 : (fabsf(a[1]) <= fabsf(a[2]) ? 1 : 2);
+        e[k] = 1.0f;
+        float d = a[k];
+        float w[3] = {e[0] - d * a[0], e[1] - d * a[1], e[2] - d * a[2]};
+        float wn = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        U[1] = w[0] / wn; U[4] = w[1] / wn; U[7] = w[2] / wn;
+    }
+    float c2 = U[2] * U[2] + U[5] * U[5] + U[8] * U[8];
+    if (c2 < 0.5f) {
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+    /* canonicalise to proper rotations, sign on the last singular value */
+    float dU = U[0] * (U[4] * U[8] - U[5] * U[7]) - U[1] * (U[3] * U[8] - U[5] * U[6]) + U[2] * (U[3] * U[7] - U[4] * U[6]);
+    if (dU < 0) { U[2] = -U[2]; U[5] = -U[5]; U[8] = -U[8]; S[2] = -S[2]; }
+    float dV = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+    if (dV < 0) { V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8]; S[2] = -S[2]; }
+}
+
 static void svd3(const real *A, real *U, real *S, real *V) {
+    if (sizeof(real) == 4) {
+        float a[9], u[9], s[3], v[9];
+        for (int i = 0; i < 9; ++i) a[i] = (float)A[i];
+        svd3_f32(a, u, s, v);
+        for (int i = 0; i < 9; ++i) { U[i] = (real)u[i]; V[i] = (real)v[i]; }
+        for (int i = 0; i < 3; ++i) S[i] = (real)s[i];
+        return;
+    }
     double a[9], u[9], s[3], v[9];
     for (int i = 0; i < 9; ++i) a[i] = (double)A[i];
     svd3_f64(a, u, s, v);

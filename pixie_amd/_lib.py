@@ -104,8 +104,12 @@ SIGNATURES = {
     "pixie_norm_finalize": (_I, [_VP, _I, _I64, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
     "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
+    "pixie_combine_class_ids": (_I, [_VP, _I, _VP, _I64, _VP, _VP]),
     "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),
     "pixie_voxel_grid_to_ncdhw": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "pixie_unscale_prediction": (_I, [_VP, _I, _I64, _D, _D, _D, _D, _D, _D, _VP, _VP]),
+    "pixie_field_points_scratch_bytes": (_I64, [C.POINTER(FieldDesc)]),
+    "pixie_field_points": (_I, [C.POINTER(FieldDesc), _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pixie_field_to_particles": (_I, [C.POINTER(FieldDesc), _VP, _I, _I, _D, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 

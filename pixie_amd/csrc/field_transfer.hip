@@ -184,9 +184,113 @@ __global__ __launch_bounds__(128) void field_knn_kernel(FieldArgs A) {
     A.material[p] = best; A.label[p] = best;
 }
 
+// unscale_prediction (pixie/voxel/map_pred_to_coords.py:41-75): channels 0..2 clipped to [-1, 1] and mapped back to
+// 10^log-range (density, E) / the linear range (nu); the class channels are copied.
+__global__ __launch_bounds__(256) void unscale_kernel(const float* __restrict__ pred, float* __restrict__ out, int channels, long S,
+                                                      float dmin, float dmax, float emin, float emax, float numin, float numax) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= S) return;
+    out[v] = unscale_log(pred[v], dmin, dmax);
+    out[S + v] = unscale_log(pred[S + v], emin, emax);
+    out[2 * S + v] = unscale_lin(pred[2 * S + v], numin, numax);
+    for (int c = 3; c < channels; ++c) out[(long)c * S + v] = pred[(long)c * S + v];
+}
+
+// The masked voxel point list of map_pred_to_ply (map_pred_to_coords.py:192-252): one record per voxel with mask > 0, in
+// C order of the grid (what numpy's boolean indexing produces).  Stable stream compaction in three launches:
+// per-workgroup counts, one scan of those, then each workgroup writes its survivors at base + rank.
+constexpr int kPtsWG = 256;
+__global__ __launch_bounds__(kPtsWG) void points_count_kernel(const uint8_t* __restrict__ mask, long S, int* __restrict__ counts) {
+    const long v = (long)blockIdx.x * kPtsWG + threadIdx.x;
+    const int keep = (v < S && mask[v] != 0) ? 1 : 0;
+    const int total = __syncthreads_count(keep);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void points_scan_kernel(int* __restrict__ counts, int nblocks, long long* __restrict__ d_count) {
+    __shared__ long long s_sum[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    long long sum = 0;
+    for (int b = b0; b < b1; ++b) sum += counts[b];
+    s_sum[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long a = (tid >= off) ? s_sum[tid - off] : 0;
+        __syncthreads();
+        s_sum[tid] += a;
+        __syncthreads();
+    }
+    long long run = s_sum[tid] - sum;   // exclusive prefix of this thread's chunk
+    for (int b = b0; b < b1; ++b) { const int c = counts[b]; counts[b] = (int)run; run += c; }   // (< 2^31 voxels)
+    if (tid == 1023) *d_count = s_sum[1023];
+}
+__global__ __launch_bounds__(kPtsWG) void points_write_kernel(FieldArgs A, const int* __restrict__ offsets, long capacity, float* __restrict__ xyz,
+                                                              float* __restrict__ dens, float* __restrict__ E, float* __restrict__ nu,
+                                                              int* __restrict__ material, float* __restrict__ conf) {
+    __shared__ int s_wave[kPtsWG / 64];
+    const long S = (long)A.D * A.H * A.W;
+    const long v = (long)blockIdx.x * kPtsWG + threadIdx.x;
+    const bool keep = v < S && A.mask[v] != 0;
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int base = offsets[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    if (!keep) return;
+    const long slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (slot >= capacity) return;
+    const int iz = (int)(v % A.W), iy = (int)((v / A.W) % A.H), ix = (int)(v / ((long)A.W * A.H));
+    xyz[3 * slot] = A.ax[ix]; xyz[3 * slot + 1] = A.ay[iy]; xyz[3 * slot + 2] = A.az[iz];
+    float d, e, n, cf; int mid;
+    voxel_props(A, v, d, e, n, mid, cf);
+    dens[slot] = d; E[slot] = e; nu[slot] = n; material[slot] = mid; conf[slot] = cf;
+}
+
 }  // namespace pixie
 
 using namespace pixie;
+
+extern "C" int pixie_unscale_prediction(const float* d_pred, int channels, int64_t spatial, double density_min, double density_max,
+                                        double E_min, double E_max, double nu_min, double nu_max, float* d_out, void* stream) {
+    PX_REQUIRE(d_pred && d_out && channels >= 3 && spatial > 0, "pixie_unscale_prediction: bad arguments");
+    hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((spatial + 255) / 256)), dim3(256), 0, as_stream(stream), d_pred, d_out, channels,
+                       (long)spatial, (float)density_min, (float)density_max, (float)E_min, (float)E_max, (float)nu_min, (float)nu_max);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int64_t pixie_field_points_scratch_bytes(const pixie_field_desc* f) {
+    if (!f || f->d <= 0 || f->h <= 0 || f->w <= 0) return 0;
+    const long S = (long)f->d * f->h * f->w;
+    return (int64_t)(((S + kPtsWG - 1) / kPtsWG) * sizeof(int));
+}
+
+extern "C" int pixie_field_points(const pixie_field_desc* f, int64_t capacity, float* d_xyz, float* d_density, float* d_E, float* d_nu,
+                                  int32_t* d_material, float* d_conf, int64_t* d_count, void* d_scratch, void* stream) {
+    PX_REQUIRE(f && d_count && d_scratch, "pixie_field_points: null argument");
+    PX_REQUIRE(f->d_pred && f->d_mask && f->d_axis_x && f->d_axis_y && f->d_axis_z, "pixie_field_points: null field pointer");
+    PX_REQUIRE(f->n_classes >= 1 && f->d > 0 && f->h > 0 && f->w > 0, "pixie_field_points: bad field shape");
+    PX_REQUIRE(capacity == 0 || (d_xyz && d_density && d_E && d_nu && d_material && d_conf), "pixie_field_points: null output with capacity > 0");
+    hipStream_t st = as_stream(stream);
+    FieldArgs A{};
+    A.pred = f->d_pred; A.mask = f->d_mask; A.ax = f->d_axis_x; A.ay = f->d_axis_y; A.az = f->d_axis_z;
+    A.ncls = f->n_classes; A.D = f->d; A.H = f->h; A.W = f->w;
+    A.dmin = (float)f->density_min; A.dmax = (float)f->density_max; A.emin = (float)f->E_min; A.emax = (float)f->E_max;
+    A.numin = (float)f->nu_min; A.numax = (float)f->nu_max;
+    const long S = (long)A.D * A.H * A.W;
+    PX_REQUIRE(S < (1l << 31), "pixie_field_points: grid too large");
+    const int nblocks = (int)((S + kPtsWG - 1) / kPtsWG);
+    int* counts = static_cast<int*>(d_scratch);
+    hipLaunchKernelGGL(points_count_kernel, dim3((unsigned)nblocks), dim3(kPtsWG), 0, st, A.mask, S, counts);
+    hipLaunchKernelGGL(points_scan_kernel, dim3(1), dim3(1024), 0, st, counts, nblocks, reinterpret_cast<long long*>(d_count));
+    if (capacity > 0)
+        hipLaunchKernelGGL(points_write_kernel, dim3((unsigned)nblocks), dim3(kPtsWG), 0, st, A, counts, (long)capacity, d_xyz, d_density, d_E,
+                           d_nu, d_material, d_conf);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int pixie_field_to_particles(const pixie_field_desc* f, const float* d_pos, int n, int k, double nn_distance_threshold,
                                         int weighted, int default_material, int default_part_label, float* d_density, float* d_E,

@@ -76,7 +76,10 @@ struct StepParams {
     float damping;
     int do_damping;
     float rpic;
-    int trace;      // timing studies: workgroups stamp s_memrealtime around their phases into g_mpm_trace
+    int trace;      // timing studies: bit 0 = workgroups stamp s_memrealtime around their phases into g_mpm_trace;
+                    // bits 8.. = ablations for bottleneck hunting (RESULTS ARE WRONG with any of them set):
+                    // 0x100 skip the LDS scatter atomics, 0x200 skip the workgroup scale reduction (fixed scale),
+                    // 0x400 skip the tile staging loads, 0x800 skip the tile publish stores
     MaterialScalars ms;
 };
 
@@ -493,7 +496,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long v, float inv_scal
 // 100 MHz timestamps -- start, tile staged, particles updated (G2P + stress), scales known, scatter done, tile published.
 constexpr int kMpmTraceItems = 32768;
 __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
-#define PX_MPM_STAMP(i) do { if (DO_G2P && DO_P2G && sp.trace && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define PX_MPM_STAMP(i) do { if (DO_G2P && DO_P2G && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
 // OCC = waves per SIMD the register allocation is held to (launch_bounds): 3 -> 168 VGPRs, no spills; 4 -> 128 VGPRs
 // (52 spilled dwords, mostly on the svd3 / slow paths); chosen at run time (set_scalar "occupancy"), same arithmetic.
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         if (DO_G2P) {
             const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng)
+            if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng && !(sp.trace & 0x400))
                 g = S.gout[((size_t)gx * ng + gy) * ng + gz];
             tv[idx] = g;
         }
@@ -567,6 +570,8 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         }
         // ---- workgroup bounds -> power-of-two scales ----
         float bp = 0.0f, bm = 0.0f;
+        if (sp.trace & 0x200) { bp = 1.0f; bm = 1e-3f; }
+        else {
         if (in.active) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -585,6 +590,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         __syncthreads();
         bp = s_red[0][0]; bm = s_red[1][0];
         for (int w = 1; w < (nthr >> 6); ++w) { bp = fmaxf(bp, s_red[0][w]); bm = fmaxf(bm, s_red[1][w]); }
+        }
         const float sP = scale_for(bp), sM = scale_for(bm);
         PX_MPM_STAMP(3);
 
@@ -595,6 +601,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             for (int k = 0; k < 9; ++k) { in.A.m[k] *= sP; in.T.m[k] *= sP; }
             p2g_scatter(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
                 const int idx = b0 + (i * kTS + j) * kTS + k;
+                if (sp.trace & 0x100) { asm volatile("" :: "v"(mom[0]), "v"(mom[1]), "v"(mom[2]), "v"(m)); return; }
                 atomicAdd(&ta[0][idx], to_fixed(mom[0]));
                 atomicAdd(&ta[1][idx], to_fixed(mom[1]));
                 atomicAdd(&ta[2][idx], to_fixed(mom[2]));
@@ -607,6 +614,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         if (nchunks == 1) {
             // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
             float4* dst = S.part + (size_t)blockIdx.x * kTN;
+            if (!(sp.trace & 0x800))
             for (int idx = tid; idx < kTN; idx += nthr)
                 dst[staged_index(idx >> 6, (idx >> 3) & 7, idx & 7)] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
                                        from_fixed(ta[3][idx], iM));
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             __syncthreads();
         }
         PX_MPM_STAMP(5);
-        if (DO_G2P && DO_P2G && sp.trace && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
+        if (DO_G2P && DO_P2G && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
             g_mpm_trace[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 }

@@ -283,6 +283,16 @@ __global__ void combine_kernel(const float* __restrict__ logits, int ncls, const
     if (argmax_out) argmax_out[i] = best;
 }
 
+// save_predictions (inference_combined.py:186-195) from class ids: combined[3 + k] = (seg_pred == k)
+__global__ void combine_ids_kernel(const int* __restrict__ seg, int ncls, const float* __restrict__ cont, long spatial,
+                                   float* __restrict__ combined) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= spatial) return;
+    const int id = seg[i];
+    for (int c = 0; c < 3; ++c) combined[(size_t)c * spatial + i] = cont[(size_t)c * spatial + i];
+    for (int c = 0; c < ncls; ++c) combined[(size_t)(3 + c) * spatial + i] = (c == id) ? 1.0f : 0.0f;
+}
+
 template <int C>
 static int launch_attention(const float* qkv, float* out, int T, hipStream_t st) {
     const size_t merge = ((size_t)ATT_WAVES * C * ATT_BQ + 2 * ATT_WAVES * ATT_BQ) * sizeof(float);
@@ -381,6 +391,15 @@ extern "C" int pixie_attention_forward(const float* d_qkv, float* d_out, int cha
         case 256: return launch_attention<256>(d_qkv, d_out, tokens, st);
         default: return set_error("pixie_attention_forward: unsupported channel count %d (32/64/128/256)", channels);
     }
+}
+
+extern "C" int pixie_combine_class_ids(const int32_t* d_seg_pred, int num_classes, const float* d_cont, int64_t spatial, float* d_combined,
+                                       void* stream) {
+    PX_REQUIRE(d_seg_pred && d_cont && d_combined && num_classes > 0 && spatial > 0, "pixie_combine_class_ids: bad arguments");
+    hipLaunchKernelGGL(combine_ids_kernel, dim3(cdiv(spatial, 256)), dim3(256), 0, as_stream(stream), d_seg_pred, num_classes, d_cont,
+                       (long)spatial, d_combined);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial, float* d_combined,

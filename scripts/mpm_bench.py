@@ -24,6 +24,8 @@ def main():
     apply_scene(s, sc)
     if resort > 0:
         s._set_scalar("resort_interval", resort)
+    if os.environ.get("PIXIE_MPM_TRACE"):
+        s._set_scalar("trace", int(os.environ["PIXIE_MPM_TRACE"], 0))
     if os.environ.get("PIXIE_MPM_OCC"):
         s._set_scalar("occupancy", int(os.environ["PIXIE_MPM_OCC"]))
     if os.environ.get("PIXIE_MPM_ITEM_CAP"):
@@ -40,7 +42,7 @@ def main():
     p_ms, g_ms, nl = s.kernel_times()
     s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
-    print(f"n={n} ng={ng} resort={resort} {scenario} occ={os.environ.get('PIXIE_MPM_OCC', '3')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', '256')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
+    print(f"n={n} ng={ng} resort={resort} {scenario} occ={os.environ.get('PIXIE_MPM_OCC', '3')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', '256')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
           f"rebins {int(s._get_scalar('n_rebins'))} slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "

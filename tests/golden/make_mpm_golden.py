@@ -14,8 +14,8 @@ Per checkpoint (substeps 20, 100, 500, 1000) the fixture holds, from the float64
   x, v, F_trial, C   of every STRIDE-th particle (caller order), float64
   norms              L2 norms over ALL particles of x - x0, v, C, F_trial - I   (whole-population parity)
   momentum, com      sum(m v), sum(m x) / sum(m) over all particles
-and, from the float32 run of the same oracle, `drift_*`: its distance from the float64 run over all particles (x, the
-displacement, v, C, F_trial) -- the rounding-error floor that any float32 implementation (the reference's Warp kernels
+and, from the float32 run of the same oracle, `drift_*` / `drift_agg_*`: its distance from the float64 run over all
+particles (x, the displacement, v, C, F_trial; the norm ratios, total momentum and centre of mass) -- the rounding-error floor that any float32 implementation (the reference's Warp kernels
 included) is entitled to, which the GPU test uses to scale its tolerances.
 """
 import os
@@ -79,7 +79,14 @@ def main(out_name="mpm_config3.npz", checkpoints=CHECKPOINTS):
         res[f"com_{cp}"] = (mass[:, None] * s64["x"]).sum(0) / mass.sum()
         res[f"drift_{cp}"] = np.array([rel(s32["x"], s64["x"]), rel(s32["x"] - x0, s64["x"] - x0), rel(s32["v"], s64["v"]),
                                        rel(s32["C"], s64["C"]), rel(s32["F_trial"], s64["F_trial"])])
-        print(cp, "norms", res[f"norms_{cp}"], "drift (x, disp, v, C, F)", res[f"drift_{cp}"], flush=True)
+        # the same float32 run's whole-population aggregates: |norm ratio - 1| (displacement, v, C, F - I), momentum error
+        # relative to sum(m) * rms|v|, centre-of-mass error (absolute)
+        n32 = np.array([np.linalg.norm(s32["x"] - x0), np.linalg.norm(s32["v"]), np.linalg.norm(s32["C"]), np.linalg.norm(s32["F_trial"] - eye)])
+        v_rms = np.linalg.norm(s64["v"]) / np.sqrt(N)
+        res[f"drift_agg_{cp}"] = np.concatenate([np.abs(n32 / res[f"norms_{cp}"] - 1.0),
+                                                 [np.linalg.norm((mass[:, None] * s32["v"]).sum(0) - res[f"momentum_{cp}"]) / (mass.sum() * v_rms),
+                                                  np.abs((mass[:, None] * s32["x"]).sum(0) / mass.sum() - res[f"com_{cp}"]).max()]])
+        print(cp, "norms", res[f"norms_{cp}"], "drift (x, disp, v, C, F)", res[f"drift_{cp}"], "aggregates", res[f"drift_agg_{cp}"], flush=True)
     np.savez_compressed(os.path.join(HERE, out_name), **res)
     print("wrote", out_name, f"{time.time() - t0:.0f} s")
 

@@ -264,17 +264,21 @@ def test_rollout_parity_config3(hip_device):
         dC = d_C * float(g[f"norms_{cp}"][2]) / np.sqrt(n) / c_scale
         norms = np.array([np.linalg.norm(x - x0), np.linalg.norm(v), np.linalg.norm(C), np.linalg.norm(F - np.eye(3))])
         e_norm = np.abs(norms / g[f"norms_{cp}"] - 1.0)
-        p = (mass[:, None] * v).sum(0)
-        e_p = float(np.linalg.norm(p - g[f"momentum_{cp}"]) / (np.linalg.norm(mass) * v_rms * np.sqrt(n) / np.sqrt(n)))
+        e_p = float(np.linalg.norm((mass[:, None] * v).sum(0) - g[f"momentum_{cp}"]) / (mass.sum() * float(g[f"norms_{cp}"][1]) / np.sqrt(n)))
         e_com = float(np.abs((mass[:, None] * x).sum(0) / mass.sum() - g[f"com_{cp}"]).max())
+        agg = g[f"drift_agg_{cp}"]   # the float32 oracle's own |norm ratio - 1| x4, momentum error, centre-of-mass error
         print(f"config 3 @ substep {cp}: x {e_x:.2e}, F_trial {e_F:.2e}, displacement {e_disp:.2e} (f32 oracle {d_disp:.2e}), "
-              f"v {e_v:.2e} (f32 oracle {dv:.2e}), C {e_C:.2e} (f32 oracle {dC:.2e}); whole-population norms off by "
-              f"{e_norm.max():.2e}, momentum {e_p:.2e}, centre of mass {e_com:.2e}")
+              f"v {e_v:.2e} (f32 oracle {dv:.2e}), C {e_C:.2e} (f32 oracle {dC:.2e}); whole population: norms off by "
+              f"{e_norm.max():.2e} (f32 oracle {agg[:4].max():.2e}), momentum {e_p:.2e} ({agg[4]:.2e}), centre of mass {e_com:.2e} ({agg[5]:.2e})")
         assert np.isfinite(x).all() and np.isfinite(v).all()
         assert e_x < 1e-4 and e_F < 1e-4
         assert e_disp < max(1e-4, 4 * d_disp)
         assert e_v < max(1e-4, 4 * dv) and e_C < max(1e-4, 4 * dC)
-        assert e_norm[0] < max(1e-4, 4 * d_disp) and e_norm[3] < 1e-3 and e_com < 1e-6
+        # aggregates over all 100 000 particles: systematic (not averaging-out) errors show here.  float32 positions lose
+        # the part of dt * v below half an ulp of x (dt * v ~ 1e-7 ... 1e-6 against ulp(x) = 1.2e-7 in this quiet scene),
+        # in the oracle's float32 build exactly as on the device, hence the float32 oracle's own numbers as the yardstick
+        assert (e_norm < np.maximum(1e-4, 4 * agg[:4])).all(), (e_norm, agg[:4])
+        assert e_p < max(1e-4, 4 * agg[4]) and e_com < max(1e-7, 4 * agg[5])
     assert h.out_of_bounds == 0 and int(g["oob"][0]) == 0
     assert abs(h.time - 1000 * sc["dt"]) < 1e-9
 

@@ -137,12 +137,14 @@ def test_device_svd_matches_oracle_convention():
 @pytest.mark.parametrize("material,scale,ys", [(0, 0.05, 0.0), (0, 1e-3, 0.0), (0, 0.3, 0.0), (1, 0.08, 2.0e3), (1, 0.01, 1.0e9), (2, 0.05, 0.0), (3, 0.08, 1.0e3),
                                                (5, 0.08, 2.0e3), (6, 0.05, 0.0)])
 def test_device_stress_matches_oracle(material, scale, ys):
-    """return_map_and_stress of mpm_math.h (host build) vs the C oracle's compute_stress on the same F_trial."""
+    """return_map_and_stress of mpm_math.h (host build) vs the C oracle's compute_stress on the same F_trial.  The
+    float64 oracle is the yardstick (the float32 build now carries the rounding noise of a single-precision SVD, which
+    at a strain of 1e-3 is 1e-4 of the fixed-corotated stress by itself)."""
     lib = _harness.load()
     rng = np.random.default_rng(10 + material)
     n = 3000
     sc = mpm_ball_scene(n, seed=1)
-    o = make_oracle(sc, "f32")
+    o = make_oracle(sc, "f64")
     sc["bcs"] = []; sc["fix_ground"] = None
     apply_scene(o, sc)
     Ft = np.ascontiguousarray(_rand_F(rng, n, scale))
@@ -153,8 +155,7 @@ def test_device_stress_matches_oracle(material, scale, ys):
     o._lib.mpm_set_scalar(o._h, b"xi", 0.05)
     o._lib.mpm_set_scalar(o._h, b"plastic_viscosity", 10.0)
     o.finalize_mu_lam_bulk()
-    mu = o.field("mu").copy(); lam = o.field("lam").copy(); bulk = o.field("bulk").copy()
-    ysv = o.field("yield_stress").copy()
+    mu, lam, bulk, ysv = (o.field(f).astype(np.float32) for f in ("mu", "lam", "bulk", "yield_stress"))
     mat = np.full(n, material, np.int32)
     F = np.zeros((n, 3, 3), np.float32); tau = np.zeros((n, 3, 3), np.float32)
     alpha = float(np.sqrt(2 / 3) * 2 * np.sin(25 / 180 * 3.14159265) / (3 - np.sin(25 / 180 * 3.14159265)))
