@@ -186,6 +186,11 @@ typedef struct pixie_conv_desc {
      * is too small to fill the chip (the 16^3 / 32^3 levels) split their channel chunks over up to 8 workgroup slices
      * (deterministic: partial outputs are added in a fixed order); such layers do not produce d_out_stats. */
     void* d_workspace;
+    /* Output extent, 0 = the natural size ((in * (upsample ? 2 : 1) + 2 pad - ksize) / stride + 1).  A smaller value crops
+     * the trailing planes / rows / columns: the odd-grid crop h[..., :-1] that MyUNetModel.forward applies to an
+     * up-sampled tensor before concatenating it with an odd-sized skip tensor (diffusion_network.py:925-930), done by not
+     * computing the cropped voxels (d_out, d_residual and the output statistics all have the cropped extent). */
+    int32_t out_d, out_h, out_w;
 } pixie_conv_desc;
 
 /* Repack an nn.Conv3d / nn.Conv1d weight (c_out, c_in, k,k,k) into the kernel's

@@ -49,7 +49,8 @@ class ConvDesc(C.Structure):
                 ("d_w16", C.c_void_p), ("d_in_amax0", C.c_void_p), ("d_in_amax1", C.c_void_p),
                 ("in_bound", C.c_float),
                 ("d_out_stats", C.c_void_p), ("d_out_amax", C.c_void_p),
-                ("d_workspace", C.c_void_p)]
+                ("d_workspace", C.c_void_p),
+                ("out_d", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32)]
 
 
 class FieldDesc(C.Structure):

@@ -18,6 +18,12 @@ ARCH = "gfx950"
 SOURCES = ["common.hip", "mpm.hip", "unet_ops.hip", "conv3d_mfma.hip", "conv3d_f16x3.hip", "field_transfer.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
+# Per-file flags.  mpm.hip: hipcc's SLP vectoriser turns a third of the fused MPM kernel's fp32 arithmetic into packed
+# v_pk_* instructions, each of which needs its operands in aligned register pairs: 168 VGPRs (3 waves per SIMD) and
+# ~340 extra v_mov per wave to shuffle values into place.  A packed op issues in ~5.7 cycles against 4.5 for a scalar one
+# (scripts/microbench/valu_rate.hip), so the packing saves little even before the moves.  Without it the same kernel needs
+# 96 VGPRs (5 waves per SIMD) and no spills.
+EXTRA_FLAGS = {"mpm.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -47,9 +53,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             continue
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(obj)
-        if not force and _newer(obj, [sp] + headers):
+        if not force and _newer(obj, [sp, os.path.abspath(__file__)] + headers):
             continue
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -854,6 +854,9 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
     const int pad = d->ksize == 3 ? 1 : 0;
     a.stride = d->stride;
     a.OD = (a.LD + 2 * pad - d->ksize) / a.stride + 1; a.OH = (a.LH + 2 * pad - d->ksize) / a.stride + 1; a.OW = (a.LW + 2 * pad - d->ksize) / a.stride + 1;
+    if (d->out_d > 0) a.OD = std::min(a.OD, (int)d->out_d);   // odd-grid crop (diffusion_network.py:925-930)
+    if (d->out_h > 0) a.OH = std::min(a.OH, (int)d->out_h);
+    if (d->out_w > 0) a.OW = std::min(a.OW, (int)d->out_w);
     a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     const long ovol = (long)a.OD * a.OH * a.OW;
     int MB = (a.coutp >= 64) ? 2 : 1;
@@ -918,6 +921,9 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     const int pad = d->ksize == 3 ? 1 : 0;
     a.stride = d->stride;
     a.OD = (a.LD + 2 * pad - d->ksize) / a.stride + 1; a.OH = (a.LH + 2 * pad - d->ksize) / a.stride + 1; a.OW = (a.LW + 2 * pad - d->ksize) / a.stride + 1;
+    if (d->out_d > 0) a.OD = std::min(a.OD, (int)d->out_d);   // odd-grid crop (diffusion_network.py:925-930)
+    if (d->out_h > 0) a.OH = std::min(a.OH, (int)d->out_h);
+    if (d->out_w > 0) a.OW = std::min(a.OW, (int)d->out_w);
     a.pro_a = d->d_pro_a; a.pro_b = d->d_pro_b; a.gamma = d->d_gamma; a.beta = d->d_beta; a.act = d->act;
     a.w16 = reinterpret_cast<const uint4*>(d->d_w16); a.bias = d->d_bias; a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     a.residual = d->d_residual; a.out = d->d_out;

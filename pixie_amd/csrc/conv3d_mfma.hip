@@ -268,6 +268,9 @@ extern "C" int pixie_conv3d_forward(const pixie_conv_desc* d, void* stream) {
     a.OD = (a.LD + 2 * pad - d->ksize) / a.stride + 1;
     a.OH = (a.LH + 2 * pad - d->ksize) / a.stride + 1;
     a.OW = (a.LW + 2 * pad - d->ksize) / a.stride + 1;
+    if (d->out_d > 0) a.OD = std::min(a.OD, (int)d->out_d);   // odd-grid crop (diffusion_network.py:925-930)
+    if (d->out_h > 0) a.OH = std::min(a.OH, (int)d->out_h);
+    if (d->out_w > 0) a.OW = std::min(a.OW, (int)d->out_w);
     a.pro_a = d->d_pro_a; a.pro_b = d->d_pro_b; a.gamma = d->d_gamma; a.beta = d->d_beta; a.act = d->act;
     a.w = d->d_w; a.bias = d->d_bias; a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     a.residual = d->d_residual; a.out = d->d_out;

@@ -498,8 +498,10 @@ constexpr int kMpmTraceItems = 32768;
 __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
 #define PX_MPM_STAMP(i) do { if (DO_G2P && DO_P2G && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
-// OCC = waves per SIMD the register allocation is held to (launch_bounds): 3 -> 168 VGPRs, no spills; 4 -> 128 VGPRs
-// (52 spilled dwords, mostly on the svd3 / slow paths); chosen at run time (set_scalar "occupancy"), same arithmetic.
+// OCC = waves per SIMD the register allocation is held to (launch_bounds).  Built without the SLP vectoriser (see
+// pixie_amd/build.py) the kernel needs 96 VGPRs -> 5 waves per SIMD with no spills (with it: 168 VGPRs, 3 waves, and
+// 20 % slower); 6 -> 80 VGPRs with ~20 spilled dwords (measured slower: 86 vs 81 us at 1 M particles).  Chosen at run
+// time (set_scalar "occupancy"), same arithmetic.
 template <bool DO_G2P, bool DO_P2G, int OCC>
 __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
@@ -529,10 +531,11 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     __syncthreads();
     PX_MPM_STAMP(1);
 
-    // One chunk of <= 256 particles per work item.  (Looping a workgroup over several chunks that share one tile --
-    // folding each chunk's integer sums into an fp32 tile tf -- halves the staged-tile traffic of large scenes, but
-    // the loop makes hipcc 7.2 spill ~190 VGPRs in this kernel and the rollout ran 2.5x slower; the code path is kept
-    // for a later round, the re-binning always emits single-chunk items.)
+    // One chunk of <= 256 particles per work item.  Sharing one tile between more particles was measured both ways and
+    // loses: (a) a workgroup looping over several 256-particle chunks (integer sums folded into an fp32 tile tf between
+    // chunks) -- hipcc 7.2 keeps 176 VGPRs live across the loop (3 waves per SIMD instead of 5); (b) work items of 384 ...
+    // 1024 threads -- 107 ... 132 us per launch at 1 M particles against 81 us for 256 (r2g): every barrier then waits
+    // for the slowest of 6 ... 16 waves.  The per-item costs (staging, zeroing, publish) are the smaller evil.
     constexpr int nchunks = 1;
     {
         constexpr int ch = 0;
@@ -1174,7 +1177,7 @@ struct pixie_mpm {
     unsigned long long slow_at_rebin = 0;
     unsigned long long lost_seen = 0;        // oob[0] + oob[2] as read back at the last re-binning
     int2* blk_items = nullptr;               // per block: (first work item, item count)
-    int occupancy = 3;                       // register-allocation target of the fused kernel (waves per SIMD): 3, 4 or 5
+    int occupancy = 5;                       // register-allocation target of the fused kernel (waves per SIMD): 5 or 6
     int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
     bool pmods_were_active = false;
@@ -1357,20 +1360,19 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        if (h->occupancy >= 5) hipLaunchKernelGGL((mpm_block_kernel<true, true, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
-        else if (h->occupancy == 4) hipLaunchKernelGGL((mpm_block_kernel<true, true, 4>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
-        else hipLaunchKernelGGL((mpm_block_kernel<true, true, 3>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+        if (h->occupancy >= 6) hipLaunchKernelGGL((mpm_block_kernel<true, true, 6>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+        else hipLaunchKernelGGL((mpm_block_kernel<true, true, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
     } else {
         if (g2p) {
             PModSet none{};
-            hipLaunchKernelGGL((mpm_block_kernel<true, false, 3>), grid, dim3(h->item_cap), 0, st, h->S, sp, none);
+            hipLaunchKernelGGL((mpm_block_kernel<true, false, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, none);
         }
         if (p2g) {
             if (!fused_mods) {
                 for (const PModDev& m : ordered)
                     hipLaunchKernelGGL(pmod_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, m);
             }
-            hipLaunchKernelGGL((mpm_block_kernel<false, true, 3>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+            hipLaunchKernelGGL((mpm_block_kernel<false, true, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
         }
     }
     if (e0) {
@@ -1619,7 +1621,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
     else if (k == "trace") h->trace = (int)value;
-    else if (k == "occupancy") { PX_REQUIRE(value == 3 || value == 4 || value == 5, "occupancy must be 3, 4 or 5 waves per SIMD"); h->occupancy = (int)value; }
+    else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);

@@ -8,8 +8,9 @@ Warp arrays and now pass torch tensors).  All compute is in libpixie_hip.so (csr
 this file only marshals arguments.  There is no CPU path.
 
 Differences a caller can observe, by design:
-  * export_*_to_torch return fresh tensors in the caller's particle order instead of zero-copy
-    aliases of solver memory (the solver keeps particles in its own SoA layout);
+  * export_*_to_torch return one persistent tensor per field in the caller's particle order, refreshed in
+    place by each export call, instead of live zero-copy aliases of solver memory (the solver keeps
+    particles block-sorted in SoA rows); get_field() returns fresh tensors;
   * `run(dt, n)` / `p2g2p_n` step n substeps in one call (2 launches per substep, no host sync);
     `p2g2p(step, dt)` is `run(dt, 1)`.
 """
@@ -192,9 +193,11 @@ class MPM_Simulator_WARP:
         check(_lib.load().pixie_mpm_set_field(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel(), self._stream),
               f"set_field({name})")
 
-    def get_field(self, name):
+    def get_field(self, name, out=None):
         n, g = self.n_particles, self.n_grid
-        if name in _INT_FIELDS:
+        if out is not None:
+            pass
+        elif name in _INT_FIELDS:
             out = torch.empty(n, dtype=torch.int32, device=self.device)
         elif name in _FLOAT_FIELDS:
             k = _FLOAT_FIELDS[name]
@@ -371,28 +374,40 @@ class MPM_Simulator_WARP:
         if tensor_C is not None:
             self.set_field("C", torch.reshape(tensor_C, (-1, 9)))
 
+    def _export_view(self, key, shape, dtype=torch.float32):
+        """The reference's export_*_to_torch return zero-copy aliases of the Warp arrays (wp.to_torch, :659-741): no
+        allocation per call and the same storage every time.  The solver keeps particles block-sorted in SoA rows, so a
+        live alias in the caller's order cannot exist; the closest equivalent is ONE persistent tensor per field that
+        every export call refreshes in place (one gather launch) and returns -- callers that hold on to the tensor see it
+        updated by the next export call, never a new allocation per rendered frame (gs_simulation.py:591-600)."""
+        views = self.__dict__.setdefault("_views", {})
+        t = views.get(key)
+        if t is None or t.device != self.device or tuple(t.shape) != tuple(shape):
+            t = views[key] = torch.empty(shape, dtype=dtype, device=self.device)
+        return t
+
     def export_particle_x_to_torch(self):
-        return self.get_field("x")
+        return self.get_field("x", out=self._export_view("x", (self.n_particles, 3)))
 
     def export_particle_v_to_torch(self):
-        return self.get_field("v")
+        return self.get_field("v", out=self._export_view("v", (self.n_particles, 3)))
 
     def export_particle_stress_to_torch(self):
-        return self.get_field("stress").reshape(-1, 3, 3)
+        return self.get_field("stress", out=self._export_view("stress", (self.n_particles, 9))).reshape(-1, 3, 3)
 
     def export_particle_F_to_torch(self):
-        return self.get_field("F").reshape(-1, 9)
+        return self.get_field("F", out=self._export_view("F", (self.n_particles, 9)))
 
     def export_particle_C_to_torch(self):
-        return self.get_field("C").reshape(-1, 9)
+        return self.get_field("C", out=self._export_view("C", (self.n_particles, 9)))
 
     def export_particle_R_to_torch(self, device="cuda:0"):
-        out = torch.empty((self.n_particles, 9), dtype=torch.float32, device=self.device)
+        out = self._export_view("R", (self.n_particles, 9))
         check(_lib.load().pixie_mpm_export_R(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_R")
         return out
 
     def export_particle_cov_to_torch(self, device="cuda:0"):
-        out = torch.empty(self.n_particles * 6, dtype=torch.float32, device=self.device)
+        out = self._export_view("cov", (self.n_particles * 6,))
         check(_lib.load().pixie_mpm_export_cov(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_cov")
         return out
 

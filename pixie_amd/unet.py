@@ -90,7 +90,7 @@ class HipOps:
              affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
              residual: Optional[torch.Tensor] = None, w16: Optional[torch.Tensor] = None,
              in_amax: Optional[Sequence[torch.Tensor]] = None, in_bound: float = 0.0,
-             out_amax: Optional[torch.Tensor] = None):
+             out_amax: Optional[torch.Tensor] = None, out_size: Optional[Tuple[int, int, int]] = None):
         """Returns the output tensor; with `out_amax` (f16x3 path) returns (output, channel sums float64 (c_out, 2))
         computed in the conv epilogue, and atomicMax'es |output|max into out_amax."""
         x0 = parts[0]
@@ -101,8 +101,11 @@ class HipOps:
         od = (d * up + 2 * pad - ksize) // stride + 1
         oh = (h * up + 2 * pad - ksize) // stride + 1
         ow = (w * up + 2 * pad - ksize) // stride + 1
-        out = torch.empty((cout, od, oh, ow), device=self.device, dtype=torch.float32)
         desc = ConvDesc()
+        if out_size is not None:   # odd-grid crop (diffusion_network.py:925-930): the cropped voxels are never computed
+            od, oh, ow = min(od, int(out_size[0])), min(oh, int(out_size[1])), min(ow, int(out_size[2]))
+            desc.out_d, desc.out_h, desc.out_w = od, oh, ow
+        out = torch.empty((cout, od, oh, ow), device=self.device, dtype=torch.float32)
         desc.d_in0 = x0.data_ptr(); desc.c0 = cin0
         desc.d_in1 = x1.data_ptr() if x1 is not None else None
         desc.c1 = x1.shape[0] if x1 is not None else 0
@@ -280,18 +283,20 @@ class UNetRunner:
 
     def _conv(self, cache: dict, parts: List[torch.Tensor], wkey: str, cout: int, ksize: int, *, stride: int = 1,
               upsample: bool = False, pro=None, affine_key: Optional[str] = None, act: int = ACT_NONE,
-              residual: Optional[torch.Tensor] = None, bound: float = 0.0) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, bound: float = 0.0, out_size=None) -> torch.Tensor:
         """One convolution launch.  `bound` bounds the magnitude of the prologue's output (needed by the f16x3
         kernel to place the tensor in the fp16 range); raw inputs use their device-side |x|max instead."""
         ops = self.ops
         affine = (self.p[affine_key + ".weight"], self.p[affine_key + ".bias"]) if affine_key else None
         if not (self._f16x3 and ops.f16x3_ok(parts, stride)):
             return ops.conv(parts, self._w(wkey), self._b(wkey), cout, ksize, stride=stride, upsample=upsample, pro=pro,
-                            affine=affine, act=act, residual=residual)
+                            affine=affine, act=act, residual=residual, **({"out_size": out_size} if out_size is not None else {}))
         if pro is None and affine is None:
             kw = dict(in_amax=[self._amax(cache, t) for t in parts])
         else:
             kw = dict(in_bound=bound)
+        if out_size is not None:
+            kw["out_size"] = out_size
         if self.fuse_stats:
             # the output's channel sums and |x|max come out of the conv epilogue: no separate pass over the tensor
             slot = self._new_slot(cache, parts[0].device)
@@ -331,7 +336,7 @@ class UNetRunner:
         att = ops.attention(qkv.reshape(3 * c, spatial), c, spatial).reshape(x.shape)
         return self._conv(cache, [att], p + ".proj_out", c, 1, residual=x)
 
-    def _block(self, b: Block, parts: List[torch.Tensor], cache: dict) -> torch.Tensor:
+    def _block(self, b: Block, parts: List[torch.Tensor], cache: dict, up_size=None) -> torch.Tensor:
         if b.kind == "res":
             return self._res(b, parts, cache)
         assert len(parts) == 1
@@ -341,7 +346,9 @@ class UNetRunner:
         if b.kind == "down":
             return self._conv(cache, [x], b.prefix + ".op", b.cout, 3, stride=2)
         if b.kind == "up":
-            return self._conv(cache, [x], b.prefix + ".conv", b.cout, 3, upsample=True)
+            # `up_size`: spatial size of the skip tensor this output will be concatenated with; on odd grids it is one
+            # less than 2 * sp and the reference crops h[..., :-1] per axis (diffusion_network.py:925-930)
+            return self._conv(cache, [x], b.prefix + ".conv", b.cout, 3, upsample=True, out_size=up_size)
         raise ValueError(b.kind)
 
     def forward(self, feat: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
@@ -388,11 +395,10 @@ class UNetRunner:
                 taps[b.prefix] = h
         for seq in plan.output_blocks:
             skip = hs.pop()
-            if tuple(skip.shape[1:]) != tuple(h.shape[1:]):
-                raise NotImplementedError("odd grid sizes (the crop at diffusion_network.py:925-930) are not supported")
+            assert tuple(skip.shape[1:]) == tuple(h.shape[1:]), (skip.shape, h.shape)   # the up-conv already cropped
             parts = [h, skip]  # th.cat([h, hs.pop()], dim=1), :932 -- never materialised
             for b in seq:
-                h = self._block(b, parts, cache)
+                h = self._block(b, parts, cache, up_size=tuple(hs[-1].shape[1:]) if (b.kind == "up" and hs) else None)
                 parts = [h]
             if taps is not None:
                 taps[seq[0].prefix.rsplit(".", 1)[0]] = h

@@ -14,7 +14,12 @@ class TorchRefOps:
     def pack_conv(self, weight):
         return weight.detach().to(torch.float32)
 
-    def conv(self, parts, packed_w, bias, cout, ksize, stride=1, upsample=False, pro=None, affine=None, act=0, residual=None):
+    def conv(self, parts, packed_w, bias, cout, ksize, stride=1, upsample=False, pro=None, affine=None, act=0, residual=None,
+             out_size=None):
+        if out_size is not None:   # the odd-grid crop: compute, then drop the trailing planes (the HIP kernels never compute them)
+            y = self.conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, None)
+            y = y[:, :out_size[0], :out_size[1], :out_size[2]].contiguous()
+            return y + residual if residual is not None else y
         x = torch.cat(list(parts), dim=0) if len(parts) > 1 else parts[0]
         if pro is not None:
             x = x * pro[0][:, None, None, None] + pro[1][:, None, None, None]
@@ -113,7 +118,16 @@ class TorchRefOpsF16x3(TorchRefOps):
         return self.channel_sums(x)
 
     def conv(self, parts, packed_w, bias, cout, ksize, stride=1, upsample=False, pro=None, affine=None, act=0, residual=None,
-             w16=None, in_amax=None, in_bound=0.0, out_amax=None):
+             w16=None, in_amax=None, in_bound=0.0, out_amax=None, out_size=None):
+        if out_size is not None:
+            r = self.conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, None, w16, in_amax, in_bound, None)
+            y = r[:, :out_size[0], :out_size[1], :out_size[2]].contiguous()
+            y = y + residual if residual is not None else y
+            if out_amax is None:
+                return y
+            out_amax.copy_(torch.maximum(out_amax.view(torch.float32), y.abs().max().reshape(1).float()).view(torch.int32))
+            yd = y.reshape(cout, -1).double()
+            return y, torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=1)
         if out_amax is not None:   # epilogue statistics of the f16x3 path
             y = self.conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, residual, w16, in_amax, in_bound)
             out_amax.copy_(torch.maximum(out_amax.view(torch.float32), y.abs().max().reshape(1).float()).view(torch.int32))

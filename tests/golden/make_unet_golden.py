@@ -32,6 +32,12 @@ CASES = {
                     attention_resolutions=(), grid_size=32), 0, 0),
     "noproj_attn8": (dict(feature_channels=32, cond_dim=32, model_channels=32, num_res_blocks=1, channel_mult=(1, 2),
                           attention_resolutions=(2,), grid_size=8), 3, 4),
+    # odd grid: Downsample 9 -> 5, Upsample 5 -> 10, cropped back to 9 (diffusion_network.py:925-930)
+    "odd9": (dict(feature_channels=32, cond_dim=32, model_channels=32, num_res_blocks=1, channel_mult=(1, 2),
+                  attention_resolutions=(), grid_size=9), 7, 8),
+    # two odd levels with the projector: 13 -> 7 -> 4, back up 4 -> 8 (crop 7) -> 14 (crop 13)
+    "odd13": (dict(feature_channels=64, cond_dim=32, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2),
+                   attention_resolutions=(), grid_size=13), 9, 10),
     "lightproj8": (dict(feature_channels=3, cond_dim=32, model_channels=32, num_res_blocks=1, channel_mult=(1, 2),
                         attention_resolutions=(), grid_size=8), 5, 6),
 }
@@ -73,7 +79,10 @@ def run_reference(cfg: UNetConfig, wseed: int, feat: np.ndarray) -> np.ndarray:
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])
     for name, (kw, wseed, iseed) in CASES.items():
+        if only and name not in only:
+            continue
         feat = feature_grid(kw["grid_size"], kw["feature_channels"], seed=iseed)
         res = {}
         for head, oc, off in HEADS:

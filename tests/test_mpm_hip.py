@@ -326,6 +326,13 @@ def test_exports_cov_and_rotation(hip_device):
     assert rel_l2(h.export_particle_cov_to_torch().cpu().numpy(), o.export_cov()) < 1e-5
     assert rel_l2(h.export_particle_R_to_torch().cpu().numpy(), o.export_R()) < 1e-5
     assert h.export_particle_F_to_torch().shape == (5000, 9)
+    # exports are persistent per-field tensors refreshed in place (the reference returns aliases of solver memory): no
+    # allocation per call, and a tensor the caller kept sees the next export
+    xa = h.export_particle_x_to_torch()
+    x_before = xa.clone()
+    h.run(sc["dt"], 5)
+    xb = h.export_particle_x_to_torch()
+    assert xa.data_ptr() == xb.data_ptr() and not torch.equal(x_before, xb) and torch.equal(xb, h.get_field("x"))
     assert h.mpm_state.particle_x.numpy().shape == (5000, 3)
     E = torch.full((5000,), 3.0e5)
     h.mpm_model.E = E  # gs_simulation.py:528 style assignment
