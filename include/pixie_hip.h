@@ -209,7 +209,8 @@ int64_t pixie_conv_stats_floats(const pixie_conv_desc* desc);
 int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* desc);
 int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* desc, double* d_sums, void* stream);
 /* Which kernel instantiation pixie_conv3d_forward picks for this descriptor: ksize*100 + MB*10 + NB of
- * conv3d_f16x3_kernel<ksize,MB,NB> (and its split-K factor in *slices), 0 = the exact-fp32 kernel.  For profilers that
+ * conv3d_f16x3_kernel<ksize,MB,NB> (and its split-K factor in *slices), 9324 = conv3d_f16x3_c64_fullres_kernel (the <3,2,4>
+ * code under its own symbol for the 64 -> 64 full-resolution 3^3 layers), 0 = the exact-fp32 kernel.  For profilers that
  * want to group per-launch timings by kernel name, as rocprofv3 does; no reference counterpart. */
 int pixie_conv_kernel_variant(const pixie_conv_desc* desc, int* slices);
 

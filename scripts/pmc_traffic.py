@@ -37,10 +37,10 @@ for nm, tab, ctr in (("read4", cal_f, "FETCH_SIZE"), ("read16", cal_f, "FETCH_SI
     fac[nm] = (CAL_BYTES / (c * 1024.0)) if c else None
 res = {"calibration": {"bytes_moved_per_kernel": CAL_BYTES, "factor_true_over_counter": fac,
                        "note": "counter unit KiB; factors measured with scripts/microbench/hbm_calib.hip in the same rocprofv3 passes"}}
-for tag, kernel, rd, wr in (("conv_64_64_128", "conv3d_f16x3_kernel<3, 2, 4", "read4", "write4"),
-                            ("mpm_100k_block", "mpm_block_kernel<true, true>", "read4", "write4"),
+for tag, kernel, rd, wr in (("conv_64_64_128", "conv3d_f16x3_c64_fullres_kernel", "read4", "write4"),
+                            ("mpm_100k_block", "mpm_block_kernel<true, true", "read4", "write4"),
                             ("mpm_100k_grid", "mpm_grid_block_kernel", "read16", "write16"),
-                            ("mpm_1m_block", "mpm_block_kernel<true, true>", "read4", "write4"),
+                            ("mpm_1m_block", "mpm_block_kernel<true, true", "read4", "write4"),
                             ("mpm_1m_grid", "mpm_grid_block_kernel", "read16", "write16")):
     run = tag.split("_")[0] + "_" + tag.split("_")[1] if tag.startswith("mpm") else "conv"
     f = find(read(run + "_fetch"), kernel, "FETCH_SIZE")
