@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--mpm-substeps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mpm", action="store_true")
+    ap.add_argument("--no-shipped-shape", action="store_true", help="skip the 64^3 x 768 fp16-grid sub-record")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32-MFMA sub-record of the same U-Net step")
     ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
@@ -212,6 +213,49 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     return dict(seconds=dt, steps=n_steps, voxels=world * n_steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision,
                 conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(n_steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
                 kernel_avg=prof.by_variant())
+
+
+def bench_shipped_shape(args, device):
+    """The reference's SHIPPED input shape (config/training/default.yaml:5,29: 64^3 grid, 768 CLIP channels, stored as a
+    (D, H, W, C) float16 .npy): one scene through (a) the reference's own route -- fp16 DHWC -> fp32 NCDHW loader kernel, then
+    each network's first projector conv reads the 805 MB float32 tensor -- (b) the fused route -- pixie_projector_conv0 reads
+    the 403 MB grid once for both networks -- and (c) route (a) with each network replayed as one captured HIP graph (what
+    is left when the ~800 Python -> ctypes launches per scene are out of the way).  Device-resident input, HIP-event timing."""
+    from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field, predict_material_field_from_voxel_grid
+    from pixie_amd.voxel_grid import load_voxel_grid
+    D, C = 64, 768
+    kw = dict(feature_channels=C, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4), attention_resolutions=(), grid_size=D)
+    seg, cont = SegmentationUNet(num_classes=8, **kw), RegressionUNet(out_channels=3, **kw)
+    seg.load_numpy_state(synthetic_state_dict(seg.cfg, 0)); cont.load_numpy_state(synthetic_state_dict(cont.cfg, 1000))
+    seg, cont = seg.to(device).eval(), cont.to(device).eval()
+    gen = torch.Generator(device=device).manual_seed(7)
+    grid = torch.randn((D, D, D, C), generator=gen, device=device).to(torch.float16)
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, 1e3 * (time.perf_counter() - t0) / reps
+
+    res = {"workload": f"{D}^3 x {C} float16 (D,H,W,C) voxel grid -> SegmentationUNet+RegressionUNet forward + combine, 1 scene"}
+    ms, wall = timed(lambda: predict_material_field(seg, cont, load_voxel_grid(grid, device)))
+    res["loader_then_networks"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
+    ms, wall = timed(lambda: predict_material_field_from_voxel_grid(seg, cont, grid))
+    res["fused_first_projector_conv"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
+    seg.use_graph = cont.use_graph = True
+    feat32 = load_voxel_grid(grid, device)
+    ms, wall = timed(lambda: predict_material_field(seg, cont, feat32))
+    res["networks_as_hip_graphs_fp32_input_resident"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
+    seg.use_graph = cont.use_graph = False
+    ms, wall = timed(lambda: predict_material_field(seg, cont, feat32))
+    res["networks_eager_fp32_input_resident"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
+    res["flops_per_scene"] = conv_flops(seg.cfg) + conv_flops(cont.cfg)
+    return res
 
 
 def load_traffic():
@@ -427,6 +471,7 @@ def main():
         # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120): where the HBM roofline fraction is meaningful
         m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, 300, "1m")
         ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
+        shipped = bench_shipped_shape(args, device) if (rank == 0 and world == 1 and not args.no_shipped_shape) else None
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baselines(args)
@@ -460,6 +505,8 @@ def main():
             line["mpm_1m"] = m_large
         if ft is not None:
             line["field_to_particles"] = ft
+        if shipped is not None:
+            line["shipped_shape_64x768"] = shipped
         if cpu is not None:
             line["cpu_baseline"] = cpu["unet"]
             if "mpm" in line:

@@ -239,6 +239,16 @@ int pixie_channel_affine(const float* d_x, const float* d_a, const float* d_b, f
  * (D,H,W,C) float16 by pixie/voxel/voxelize.py:86,111): .astype(float32) + permute to (C,D,H,W), on the device. */
 int pixie_voxel_grid_to_ncdhw(const void* d_feat_dhwc_f16, int d, int h, int w, int channels, float* d_out_cdhw, void* stream);
 
+/* FeatureProjector.net[0] -- Conv3d(C, c_out, 1) + bias (diffusion_network.py:556-560) -- of one or two networks applied
+ * to the voxel grid as the reference stores it: (voxels, C) float16, channels last (pixie/voxel/voxelize.py:86,111; what
+ * WG/data_utils/my_data.py:160-224 converts to float32 and permutes first).  One launch reads the grid once and writes
+ * d_out[n] = (c_out, voxels) float32 for each network n.  d_w16[n] comes from pixie_conv_pack_weights_f16x2(w, ., c_out,
+ * C, 1): the inputs are exact fp16 numbers, so only the weights are split (two f16 MFMAs per product, fp32 accumulate).
+ * Requires C % 16 == 0 and n_networks * padded(c_out) in {64, 128, 256} (the reference shapes: c_out = 128, one or two
+ * networks); other shapes go through pixie_voxel_grid_to_ncdhw + pixie_conv3d_forward. */
+int pixie_projector_conv0(const void* d_feat_dhwc_f16, int64_t voxels, int channels, int n_networks, const void* const* d_w16,
+                          const float* const* d_bias, float* const* d_out, int c_out, void* stream);
+
 /* process_batch/save_predictions (WG/trainer/inference_combined.py:124-126,186-195):
  * combined[0:3] = cont_pred; combined[3+k] = (argmax_c logits == k), ties -> lowest index. */
 int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial,
@@ -290,6 +300,36 @@ int pixie_unscale_prediction(const float* d_pred, int channels, int64_t spatial,
 int64_t pixie_field_points_scratch_bytes(const pixie_field_desc* field);
 int pixie_field_points(const pixie_field_desc* field, int64_t capacity, float* d_xyz /* [n][3] */, float* d_density, float* d_E,
                        float* d_nu, int32_t* d_material, float* d_conf, int64_t* d_count, void* d_scratch, void* stream);
+
+/* ======================================================================================
+ * (D) Particle pre-pass of the MPM program: replaces the Taichi kernels of
+ *     PG/particle_filling/filling.py that gs_simulation.py:442-482 runs before the solver is created.
+ * ====================================================================================== */
+/* densify_grids + compute_density (filling.py:13-92): for each of n Gaussians (d_pos [n][3], d_opacity [n], d_cov6 [n][6] =
+ * xx,xy,xz,yy,yz,zz) count it in its cell (d_grid_count[grid_n^3] += 1) and splat opacity * mean_corners exp(-d^T C^-1 d / 2)
+ * onto every cell within ceil(sqrt(max eigenvalue) / grid_dx) cells (d_grid_density[grid_n^3], accumulated; caller zeroes
+ * both grids).  Particles outside the grid are not counted (the reference indexes unchecked). */
+int pixie_fill_densify(const float* d_pos, const float* d_opacity, const float* d_cov6, int n, int grid_n, double grid_dx,
+                       int32_t* d_grid_count, float* d_grid_density, void* stream);
+/* fill_dense_grids (filling.py:95-121): every cell with density > density_thres and fewer than max_particles_per_cell
+ * particles is topped up: new points at (cell + u) * grid_dx, u uniform in [0,1)^3 from a counter-based hash of (seed, cell,
+ * k) -- ti.random() in the reference -- appended at d_new_particles[*d_counter ...]; *d_counter (device uint64) advances even
+ * past max_samples (nothing is written there), so the caller can detect the overflow the reference would write through. */
+int pixie_fill_dense_cells(int32_t* d_grid_count, const float* d_grid_density, int grid_n, double grid_dx, double density_thres,
+                           int max_particles_per_cell, float* d_new_particles /* [max_samples][3] */, int64_t max_samples,
+                           uint64_t* d_counter, uint32_t seed, void* stream);
+/* internal_filling with collision_search / collision_times (filling.py:124-244): an EMPTY cell whose rays in all six axis
+ * directions except exclude_dir (0:+x 1:-x 2:+y 3:-y 4:+z 5:-z) meet a cell with density > threshold, and whose ray along
+ * ray_cast_dir crosses the surface an odd number of times, is filled with max_particles_per_cell points. */
+int pixie_fill_internal_cells(int32_t* d_grid_count, const float* d_grid_density, int grid_n, double grid_dx, int max_particles_per_cell,
+                              int exclude_dir, int ray_cast_dir, double threshold, float* d_new_particles, int64_t max_samples,
+                              uint64_t* d_counter, uint32_t seed, void* stream);
+/* get_particle_volume (filling.py:247-288): d_vol[p] = grid_dx^3 / (particles in p's cell).  d_grid_count_scratch:
+ * grid_n^3 int32 of scratch (zeroed here). */
+int pixie_particle_volume(const float* d_pos, int n, int grid_n, double grid_dx, int32_t* d_grid_count_scratch, float* d_vol, void* stream);
+/* get_attr_from_closest (filling.py:383-403): d_nearest[i] = index of the original particle closest to new particle i
+ * (first minimum in index order; brute force through LDS tiles). */
+int pixie_nearest_particle(const float* d_pos, int n, const float* d_new_pos, int n_new, int32_t* d_nearest, void* stream);
 
 #ifdef __cplusplus
 }

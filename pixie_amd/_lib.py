@@ -105,12 +105,18 @@ SIGNATURES = {
     "pixie_norm_finalize": (_I, [_VP, _I, _I64, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
     "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
+    "pixie_projector_conv0": (_I, [_VP, _I64, _I, _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _I, _VP]),
     "pixie_combine_class_ids": (_I, [_VP, _I, _VP, _I64, _VP, _VP]),
     "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),
     "pixie_voxel_grid_to_ncdhw": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "pixie_unscale_prediction": (_I, [_VP, _I, _I64, _D, _D, _D, _D, _D, _D, _VP, _VP]),
     "pixie_field_points_scratch_bytes": (_I64, [C.POINTER(FieldDesc)]),
     "pixie_field_points": (_I, [C.POINTER(FieldDesc), _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pixie_fill_densify": (_I, [_VP, _VP, _VP, _I, _I, _D, _VP, _VP, _VP]),
+    "pixie_fill_dense_cells": (_I, [_VP, _VP, _I, _D, _D, _I, _VP, _I64, _VP, C.c_uint32, _VP]),
+    "pixie_fill_internal_cells": (_I, [_VP, _VP, _I, _D, _I, _I, _I, _D, _VP, _I64, _VP, C.c_uint32, _VP]),
+    "pixie_particle_volume": (_I, [_VP, _I, _I, _D, _VP, _VP, _VP]),
+    "pixie_nearest_particle": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
     "pixie_field_to_particles": (_I, [C.POINTER(FieldDesc), _VP, _I, _I, _D, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 

@@ -479,8 +479,8 @@ template <int KS, int MB, int NB, bool WS>
 __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     conv3d_f16x3_body<KS, MB, NB, WS>(A);
 }
-// The dominant layer of the BASELINE network -- 64 -> 64 channels, 3^3, stride 1, at full resolution (11 encoder convs per
-// network at 128^3: 41 % of a scene's FLOPs) -- under its own symbol, so that `rocprofv3 --kernel-trace --stats` reports it as
+// The dominant layer of the BASELINE network -- 64 -> 64 channels, 3^3, stride 1, on >= 128^3 voxels (the full-resolution
+// level: 41 % of a scene's FLOPs at 128^3; the 64^3 level has the same channel counts and stays on the template) -- under its own symbol, so that `rocprofv3 --kernel-trace --stats` reports it as
 // its own row instead of pooling it with the other shapes that share the <3,2,4> instantiation.  Same code, same results.
 __global__ __launch_bounds__(256, 2) void conv3d_f16x3_c64_fullres_kernel(Conv16Args A) {
     conv3d_f16x3_body<3, 2, 4, false>(A);
@@ -998,7 +998,8 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     // workgroup per CU
     if (g_conv_ws && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
         return launch_f16x3<3, 2, 4, true>(a, 2 * lds, grid, st);
-    if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0) {
+    if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 &&
+        (long)a.OD * a.OH * a.OW >= 128L * 128 * 128) {
         auto kern = conv3d_f16x3_c64_fullres_kernel;
         static bool attr_set = false;
         if (!attr_set) {
@@ -1061,7 +1062,8 @@ extern "C" int pixie_conv_kernel_variant(const pixie_conv_desc* d, int* slices_o
     int MB = 0, NB = 0, slices = 1;
     conv16_tiling(d, a, MB, NB, &slices);
     if (slices_out) *slices_out = slices;
-    if (d->ksize == 3 && MB == 2 && NB == 4 && d->c0 + d->c1 == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0)
+    if (d->ksize == 3 && MB == 2 && NB == 4 && d->c0 + d->c1 == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 &&
+        (long)a.OD * a.OH * a.OW >= 128L * 128 * 128)
         return 9324;   // conv3d_f16x3_c64_fullres_kernel: the <3,2,4> code under its own symbol
     return d->ksize * 100 + MB * 10 + NB;
 }

@@ -1,0 +1,121 @@
+"""Particle pre-pass of the MPM program on the device.
+
+Mirrors third_party/PhysGaussian/particle_filling/filling.py -- `fill_particles` (:291-380), `get_particle_volume`
+(:273-288), `init_filled_particles` (:406-447) -- with the same signatures, so gs_simulation.py:442-482 runs with
+    -from particle_filling.filling import *
+    +from pixie_amd.particle_filling import *
+and no Taichi.  The kernels are in csrc/particle_filling.hip; there is no CPU path.  Differences a caller can observe:
+the random offsets of new particles inside their cells come from a counter-based hash (reproducible; `seed=`) instead of
+ti.random(); `smooth=True` (mcubes.smooth, a host-side third-party routine) raises NotImplementedError; running out of
+`max_samples` raises instead of writing past the buffer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+__all__ = ["fill_particles", "get_particle_volume", "init_filled_particles"]
+
+
+def _dev(t: torch.Tensor) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.PixieHipError("pixie_amd.particle_filling needs a HIP device (no CPU fallback)")
+    return t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def density_grids(pos, opacity, cov, grid_n: int, grid_dx: float):
+    """densify_grids (:26-92): returns (count int32 (n,n,n), density float32 (n,n,n)) on the device."""
+    dev = _dev(pos)
+    pos = pos.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    opacity = opacity.detach().to(dev, torch.float32).reshape(-1).contiguous()
+    cov = cov.detach().to(dev, torch.float32).reshape(-1, 6).contiguous()
+    count = torch.zeros((grid_n,) * 3, dtype=torch.int32, device=dev)
+    density = torch.zeros((grid_n,) * 3, dtype=torch.float32, device=dev)
+    check(_lib.load().pixie_fill_densify(_p(pos), _p(opacity), _p(cov), pos.shape[0], int(grid_n), float(grid_dx), _p(count), _p(density),
+                                         _lib.current_stream_ptr()), "pixie_fill_densify")
+    return count, density
+
+
+def fill_particles(pos, opacity, cov, grid_n: int, max_samples: int, grid_dx: float, density_thres=2.0, search_thres=1.0,
+                   max_particles_per_cell=1, search_exclude_dir=5, ray_cast_dir=4, boundary: list = None, smooth: bool = False,
+                   seed: int = 0, return_grids: bool = False):
+    """filling.py:291-380.  Returns cat([pos, new particles]); with return_grids also (count, density, n_dense, n_total)."""
+    if smooth:
+        raise NotImplementedError("smooth=True runs mcubes.smooth on the host in the reference; not reproduced")
+    dev = _dev(pos)
+    lib = _lib.load()
+    pos_clone = pos.detach().to(dev, torch.float32).clone()
+    pos, opacity, cov = pos_clone, opacity.detach().to(dev, torch.float32), cov.detach().to(dev, torch.float32)
+    new_origin = None
+    if boundary is not None:
+        assert len(boundary) == 6
+        mask = torch.ones(pos_clone.shape[0], dtype=torch.bool, device=dev)
+        max_diff = 0.0
+        for i in range(3):
+            mask = torch.logical_and(mask, pos_clone[:, i] > boundary[2 * i])
+            mask = torch.logical_and(mask, pos_clone[:, i] < boundary[2 * i + 1])
+            max_diff = max(max_diff, boundary[2 * i + 1] - boundary[2 * i])
+        pos, opacity, cov = pos[mask], opacity.reshape(-1)[mask], cov.reshape(-1, 6)[mask]
+        grid_dx = max_diff / grid_n
+        new_origin = torch.tensor([boundary[0], boundary[2], boundary[4]], dtype=torch.float32, device=dev)
+        pos = pos - new_origin
+    count, density = density_grids(pos, opacity, cov, grid_n, grid_dx)
+    particles = torch.empty((int(max_samples), 3), dtype=torch.float32, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = _lib.current_stream_ptr()
+    check(lib.pixie_fill_dense_cells(_p(count), _p(density), int(grid_n), float(grid_dx), float(density_thres), int(max_particles_per_cell),
+                                     _p(particles), int(max_samples), _p(counter), int(seed) & 0xFFFFFFFF, st), "pixie_fill_dense_cells")
+    n_dense = int(counter.item())
+    print("after dense grids: ", n_dense)
+    check(lib.pixie_fill_internal_cells(_p(count), _p(density), int(grid_n), float(grid_dx), int(max_particles_per_cell), int(search_exclude_dir),
+                                        int(ray_cast_dir), float(search_thres), _p(particles), int(max_samples), _p(counter),
+                                        int(seed) & 0xFFFFFFFF, st), "pixie_fill_internal_cells")
+    fill_num = int(counter.item())
+    print("after internal grids: ", fill_num)
+    if fill_num > max_samples:
+        raise RuntimeError(f"fill_particles: {fill_num} new particles do not fit max_samples = {max_samples} "
+                           "(the reference would write past its buffer here)")
+    new = particles[:fill_num]
+    if new_origin is not None:
+        new = new + new_origin
+    out = torch.cat([pos_clone, new], dim=0)
+    if return_grids:
+        return out, count, density, n_dense, fill_num
+    return out
+
+
+def get_particle_volume(pos, grid_n: int, grid_dx: float, unifrom: bool = False):
+    """filling.py:273-288 (the misspelt keyword is the reference's)."""
+    dev = _dev(pos)
+    p = pos.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    scratch = torch.empty((grid_n,) * 3, dtype=torch.int32, device=dev)
+    vol = torch.empty(p.shape[0], dtype=torch.float32, device=dev)
+    check(_lib.load().pixie_particle_volume(_p(p), p.shape[0], int(grid_n), float(grid_dx), _p(scratch), _p(vol), _lib.current_stream_ptr()),
+          "pixie_particle_volume")
+    if unifrom:
+        return torch.mean(vol).repeat(p.shape[0])
+    return vol
+
+
+def init_filled_particles(pos, shs, cov, opacity, new_pos):
+    """filling.py:406-447: every new particle takes the SH coefficients, opacity and covariance of its nearest original one."""
+    dev = _dev(pos)
+    shs2 = shs.reshape(pos.shape[0], -1).to(dev)
+    p = pos.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    q = new_pos.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    nearest = torch.empty(q.shape[0], dtype=torch.int32, device=dev)
+    check(_lib.load().pixie_nearest_particle(_p(p), p.shape[0], _p(q), q.shape[0], _p(nearest), _lib.current_stream_ptr()), "pixie_nearest_particle")
+    idx = nearest.long()
+    shs_tensor = torch.cat([shs2, shs2[idx]], dim=0)
+    shs_tensor = shs_tensor.view(shs_tensor.shape[0], -1, 3)
+    opacity_tensor = torch.cat([opacity.to(dev), opacity.to(dev).reshape(-1)[idx].reshape(-1, 1)], dim=0)
+    cov_tensor = torch.cat([cov.to(dev), cov.to(dev).reshape(-1, 6)[idx]], dim=0)
+    return shs_tensor, opacity_tensor, cov_tensor

@@ -179,6 +179,19 @@ class HipOps:
         check(self.lib.pixie_attention_forward(_ptr(qkv), _ptr(out), channels, tokens, self.stream), "pixie_attention_forward")
         return out
 
+    def projector_conv0(self, grid_dhwc_f16: torch.Tensor, nets: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], cout: int):
+        """FeatureProjector.net[0] of one or two networks straight from the (D, H, W, C) float16 voxel grid (one read of the
+        grid): nets = [(packed f16x2 weight, bias), ...] -> [(cout, D, H, W) float32, ...]."""
+        d, h, w, c = (int(v) for v in grid_dhwc_f16.shape)
+        g = grid_dhwc_f16.contiguous()
+        outs = [torch.empty((cout, d, h, w), device=self.device, dtype=torch.float32) for _ in nets]
+        n = len(nets)
+        w_arr = (C.c_void_p * n)(*[t[0].data_ptr() for t in nets])
+        b_arr = (C.c_void_p * n)(*[(t[1].data_ptr() if t[1] is not None else None) for t in nets])
+        o_arr = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        check(self.lib.pixie_projector_conv0(_ptr(g), d * h * w, c, n, w_arr, b_arr, o_arr, cout, self.stream), "pixie_projector_conv0")
+        return outs
+
     def combine(self, logits: torch.Tensor, cont: torch.Tensor):
         ncls = logits.shape[0]
         spatial = logits.numel() // ncls
@@ -351,11 +364,12 @@ class UNetRunner:
             return self._conv(cache, [x], b.prefix + ".conv", b.cout, 3, upsample=True, out_size=up_size)
         raise ValueError(b.kind)
 
-    def forward(self, feat: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """feat: (C_feat, D, H, W) -> (out_channels, D, H, W)"""
+    def forward(self, feat: Optional[torch.Tensor], taps: Optional[dict] = None, proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat: (C_feat, D, H, W) -> (out_channels, D, H, W).  `proj0`: the output of projector.net[0] computed elsewhere
+        (pixie_projector_conv0 on the channels-last grid, shared with the other network); the pass then starts behind it."""
         cfg, ops = self.cfg, self.ops
         cache: dict = {}
-        spatial = feat[0].numel()
+        spatial = (proj0 if proj0 is not None else feat)[0].numel()
         x = feat
         pro_in, act_in, bound_in = None, ACT_NONE, 0.0
         if cfg.has_projector:  # FeatureProjector.net, diffusion_network.py:556-585
@@ -369,7 +383,7 @@ class UNetRunner:
                 bound_in = self._norm_bound(q + "1", spatial * (cfg.cond_dim // g))
             else:
                 hid = cfg.projector_hidden
-                x = self._conv(cache, [x], q + "0", hid, 1)
+                x = proj0 if proj0 is not None else self._conv(cache, [x], q + "0", hid, 1)
                 pro = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[q + "1.weight"], bias=self.p[q + "1.bias"])
                 x = self._conv(cache, [x], q + "3", hid, 3, pro=pro, act=ACT_SILU, bound=self._norm_bound(q + "1", spatial * (hid // 32)))
                 pro = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[q + "4.weight"], bias=self.p[q + "4.bias"])
@@ -427,6 +441,8 @@ class _PixieUNet(nn.Module):
             node.register_parameter(parts[-1], nn.Parameter(self._init(key, shape, shapes, gen), requires_grad=False))
         self._runner: Optional[UNetRunner] = None
         self.conv_precision = DEFAULT_PRECISION  # "f16x3" (default) or "f32" (exact-fp32 MFMA everywhere)
+        self.use_graph = os.environ.get("PIXIE_UNET_GRAPH", "0") == "1"   # replay a captured HIP graph per (shape, weights)
+        self._graphs: Dict[tuple, tuple] = {}
 
     @staticmethod
     def _init(key, shape, shapes, gen) -> torch.Tensor:
@@ -460,8 +476,36 @@ class _PixieUNet(nn.Module):
         else:
             self._runner.p = self._params()
         x = feat_grid.detach().to(torch.float32).contiguous()
+        if self.use_graph and taps is None:
+            return torch.stack([self._forward_graphed(x[n]) for n in range(x.shape[0])], dim=0)
         outs = [self._runner.forward(x[n], taps if n == 0 else None) for n in range(x.shape[0])]
         return torch.stack(outs, dim=0)
+
+    def _forward_graphed(self, x: torch.Tensor) -> torch.Tensor:
+        """One sample through a captured HIP graph.  A forward pass is ~400 kernel launches driven from Python (ctypes) with
+        ~600 allocations; at 128^3 the device hides that behind 45 ms of kernels, at 32^3 / 64^3 the host is the
+        bottleneck.  The launch sequence of a given (network, input shape, precision, parameter version) never changes, so it
+        is captured once -- after one eager pass that packs the weights and takes the host-side parameter bounds -- and
+        replayed with a single hipGraphLaunch.  Returns a copy of the graph's static output."""
+        key = (tuple(x.shape), self.conv_precision, x.device.index, tuple(p._version for p in self.parameters()))
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graphs.clear()                       # a new shape / parameter version invalidates the old capture
+            self._runner.forward(x)                    # eager warm-up: weight packing, bounds, function attributes
+            static_in = x.clone()
+            side = torch.cuda.Stream(x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):              # capture must not run on the legacy default stream
+                self._runner.forward(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._runner.forward(static_in)
+            ent = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = ent
+        static_in.copy_(x)
+        graph.replay()
+        return static_out.clone()
 
 
 class SegmentationUNet(_PixieUNet):
@@ -480,6 +524,35 @@ class RegressionUNet(_PixieUNet):
                  channel_mult: Tuple[int, ...], attention_resolutions: Tuple[int, ...], grid_size: int, out_channels: int = 3):
         super().__init__(UNetConfig(feature_channels, cond_dim, model_channels, num_res_blocks, tuple(channel_mult),
                                     tuple(attention_resolutions), grid_size, out_channels))
+
+
+@torch.no_grad()
+def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont_network: "RegressionUNet", grid_dhwc_f16: torch.Tensor):
+    """The same as predict_material_field, fed with the voxel grid as the reference stores it -- (D, H, W, C) float16,
+    `clip_features_features.npy` (pixie/voxel/voxelize.py:86,111) -- instead of the float32 (1, C, D, H, W) tensor
+    my_data.py:160-224 makes of it.  The first projector convolution of BOTH networks reads the grid once
+    (pixie_projector_conv0); the float32 NCDHW copy of the grid (4 B per feature written, 8 B read) never exists.
+    Needs both networks to have the hidden-128 projector (feature_channels > cond_dim, as shipped) and the f16x3 path."""
+    dev = next(seg_network.parameters()).device
+    g = grid_dhwc_f16
+    if g.dim() != 4 or g.dtype != torch.float16 or g.device != dev or dev.type != "cuda":
+        raise ValueError("expected a (D, H, W, C) float16 tensor on the networks' HIP device")
+    nets = (seg_network, cont_network)
+    for net in nets:
+        if net.cfg.projector_hidden is None or net.cfg.feature_channels != g.shape[3] or net.conv_precision != "f16x3":
+            raise ValueError("the fused grid path needs the hidden-128 projector, matching feature_channels and conv_precision 'f16x3'")
+        if net._runner is None or net._runner.ops.device != dev or net._runner.precision != net.conv_precision:
+            net._runner = UNetRunner(net.cfg, net._params(), HipOps(dev), precision=net.conv_precision)
+        else:
+            net._runner.p = net._params()
+    ops = seg_network._runner.ops
+    q = "projector.net.0"
+    packed = [(net._runner._w16(q), net._runner._b(q)) for net in nets]
+    x_seg, x_cont = ops.projector_conv0(g, packed, seg_network.cfg.projector_hidden)
+    seg_logits = seg_network._runner.forward(None, proj0=x_seg)[None]
+    cont_pred = cont_network._runner.forward(None, proj0=x_cont)[None]
+    combined, seg_pred = ops.combine(seg_logits[0].contiguous(), cont_pred[0].contiguous())
+    return combined[None], seg_pred[None], seg_logits, cont_pred
 
 
 _SIDE_STREAMS: Dict[str, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}

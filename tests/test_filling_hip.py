@@ -1,0 +1,102 @@
+"""GPU parity of pixie_amd/particle_filling.py (csrc/particle_filling.hip) with oracle/filling_oracle.py -- the NumPy
+restatement of the reference's Taichi kernels (PG/particle_filling/filling.py).  Integer results (cell counts, which cells
+are filled, how many points, nearest indices) must be identical; the density grid is float32 atomics against float64:
+rel-L2 <= 1e-5.  Cells whose density lies within 1e-4 (relative) of a threshold may legitimately fall either side in
+float32 and are excluded from the set comparison (and counted: they must be rare)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import filling_oracle as fo
+from tests.test_filling_oracle import shell_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("open_bottom,exclude,ppc", [(False, 5, 1), (True, 5, 2), (True, -1, 1)])
+def test_fill_particles_matches_oracle(hip_device, open_bottom, exclude, ppc):
+    from pixie_amd.particle_filling import fill_particles
+    n, dx = 32, 1.0 / 32
+    pos, op, cov = shell_scene(open_bottom=open_bottom)
+    pos32, op32, cov32 = (torch.from_numpy(a.astype(np.float32)).to(hip_device) for a in (pos, op, cov))
+    dens_thr, search_thr = 2.0, 1.0
+    out, count_d, dens_d, n_dense, n_total = fill_particles(pos32, op32[:, None], cov32, n, 200_000, dx, density_thres=dens_thr, search_thres=search_thr,
+                                                            max_particles_per_cell=ppc, search_exclude_dir=exclude, ray_cast_dir=4, seed=3, return_grids=True)
+    count0, dens = fo.densify(pos32.cpu().numpy(), op, cov32.cpu().numpy(), n, dx)
+    dens_h = dens_d.cpu().numpy()
+    assert rel_l2(dens_h, dens) < 1e-5
+    # which cells were filled: dense cells, then internal cells (on the grid as fill_dense_grids left it)
+    dense, per = fo.dense_cells(count0, dens, dens_thr, ppc)
+    count1 = np.where(dense, ppc, count0)
+    inside = fo.internal_cells(count1, dens, search_thr, exclude, 4)
+    final = np.where(inside, ppc, count1)
+    near = (np.abs(dens - dens_thr) < 1e-4 * dens_thr) | (np.abs(dens - search_thr) < 1e-4 * search_thr)
+    assert near.sum() <= 3
+    got = count_d.cpu().numpy()
+    if near.sum() == 0:
+        assert np.array_equal(got, final)
+        assert n_dense == int(per.sum()) and n_total == int(per.sum() + ppc * inside.sum())
+    else:   # a borderline cell can flip its own fill and, through the ray casts, cells on its lines: compare away from them
+        assert (got != final).sum() <= 3 * n
+    # the new particles: right number, each inside a cell that was filled, `ppc - original count` per cell
+    new = out[len(pos32):].cpu().numpy()
+    assert len(new) == n_total and torch.equal(out[:len(pos32)], pos32)
+    cell = np.floor(new / dx).astype(int)
+    assert (cell >= 0).all() and (cell < n).all()
+    hist = np.zeros((n,) * 3, int)
+    np.add.at(hist, tuple(cell.T), 1)
+    assert np.array_equal(hist, got - count0)
+    frac = new / dx - cell
+    assert 0.3 < frac.mean() < 0.7 and frac.std() > 0.2           # spread over the cell, not stuck in a corner
+    # reproducible: same seed, same points; another seed, other points in the same cells
+    again = fill_particles(pos32, op32[:, None], cov32, n, 200_000, dx, dens_thr, search_thr, ppc, exclude, 4, seed=3)
+    other = fill_particles(pos32, op32[:, None], cov32, n, 200_000, dx, dens_thr, search_thr, ppc, exclude, 4, seed=4)
+    assert len(again) == len(out) == len(other)
+    sort = lambda t: t[len(pos32):].cpu().numpy()[np.lexsort(t[len(pos32):].cpu().numpy().T)]
+    assert np.array_equal(sort(again), sort(out)) and not np.array_equal(sort(other), sort(out))
+
+
+def test_boundary_and_overflow(hip_device):
+    from pixie_amd.particle_filling import fill_particles
+    pos, op, cov = shell_scene()
+    shift = np.array([0.2, 0.1, 0.3])
+    p = torch.from_numpy((pos + shift).astype(np.float32)).to(hip_device)
+    o = torch.from_numpy(op.astype(np.float32)).to(hip_device)[:, None]
+    c = torch.from_numpy(cov.astype(np.float32)).to(hip_device)
+    bnd = [0.2, 1.2, 0.1, 1.1, 0.3, 1.3]
+    a = fill_particles(p, o, c, 32, 200_000, 123.0, boundary=bnd, seed=1)            # grid_dx is recomputed from the boundary
+    b = fill_particles(torch.from_numpy(pos.astype(np.float32)).to(hip_device), o, c, 32, 200_000, 1.0 / 32, seed=1)
+    assert len(a) == len(b)
+    # one point per filled cell here; the order of the appended points is the order the atomics fired in: sort by cell
+    na, nb = a[len(p):].cpu().numpy() - shift.astype(np.float32), b[len(p):].cpu().numpy()
+    key = lambda q: np.lexsort(np.floor(q * 32).astype(int).T)
+    assert np.allclose(na[key(na)], nb[key(nb)], atol=2e-6)
+    with pytest.raises(RuntimeError):
+        fill_particles(p, o, c, 32, 100, 1.0 / 32, boundary=bnd)
+    with pytest.raises(NotImplementedError):
+        fill_particles(p, o, c, 32, 100, 1.0 / 32, smooth=True)
+
+
+def test_particle_volume_and_init_filled(hip_device):
+    from pixie_amd.particle_filling import get_particle_volume, init_filled_particles
+    rng = np.random.default_rng(2)
+    pos = rng.uniform(0.02, 1.98, size=(20000, 3)).astype(np.float32)
+    vol = get_particle_volume(torch.from_numpy(pos).to(hip_device), 50, 2.0 / 50)
+    ref = fo.particle_volume(pos.astype(np.float64), 50, np.float64(np.float32(2.0 / 50)))
+    assert rel_l2(vol.cpu().numpy(), ref) < 1e-6
+    uni = get_particle_volume(torch.from_numpy(pos).to(hip_device), 50, 2.0 / 50, unifrom=True)
+    assert uni.shape == (20000,) and float(uni.std()) == 0.0 and abs(float(uni[0]) - ref.mean()) < 1e-6 * ref.mean()
+    old = pos[:3000]; new = rng.uniform(0.02, 1.98, size=(700, 3)).astype(np.float32)
+    shs = rng.normal(size=(3000, 16, 3)).astype(np.float32); cov = rng.normal(size=(3000, 6)).astype(np.float32)
+    opa = rng.uniform(size=(3000, 1)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(hip_device)
+    s2, o2, c2 = init_filled_particles(t(old), t(shs), t(cov), t(opa), t(new))
+    idx = fo.nearest(old, new)
+    assert s2.shape == (3700, 16, 3) and o2.shape == (3700, 1) and c2.shape == (3700, 6)
+    assert np.array_equal(s2[3000:].cpu().numpy(), shs[idx]) and np.array_equal(c2[3000:].cpu().numpy(), cov[idx])
+    assert np.array_equal(o2[3000:, 0].cpu().numpy(), opa[idx, 0]) and np.array_equal(s2[:3000].cpu().numpy(), shs)

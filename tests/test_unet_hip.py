@@ -486,6 +486,86 @@ def test_network_matches_reference_at_north_star_size(hip_device, D):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("D", [16, 32])
+def test_graph_replay_is_bit_identical_to_eager(hip_device, D):
+    """The captured HIP graph of a forward pass (pixie_amd.unet: use_graph) replays exactly the eager launch sequence:
+    outputs must be bit-identical, for a second input too (the capture holds no data), and after a parameter update the
+    graph must be re-captured."""
+    import time
+    from pixie_amd.unet import SegmentationUNet
+    kw = dict(feature_channels=64, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4),
+              attention_resolutions=(), grid_size=D)
+    net = SegmentationUNet(num_classes=8, **kw)
+    net.load_numpy_state(synthetic_state_dict(net.cfg, 0))
+    net = net.to(hip_device).eval()
+    xa = torch.from_numpy(feature_grid(D, 64, seed=1)).to(hip_device)
+    xb = torch.from_numpy(feature_grid(D, 64, seed=2)).to(hip_device)
+    net.use_graph = False
+    ea, eb = net(xa).clone(), net(xb).clone()
+    net.use_graph = True
+    ga, gb, ga2 = net(xa).clone(), net(xb).clone(), net(xa).clone()
+    assert torch.equal(ga, ea) and torch.equal(gb, eb) and torch.equal(ga2, ea)
+    assert len(net._graphs) == 1
+    torch.cuda.synchronize()
+    t = {}
+    for mode in (False, True):
+        net.use_graph = mode
+        net(xa); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            net(xa)
+        torch.cuda.synchronize()
+        t[mode] = (time.perf_counter() - t0) / 5
+    print(f"{D}^3 forward: eager {1e3 * t[False]:.2f} ms, graph replay {1e3 * t[True]:.2f} ms")
+    # a parameter update invalidates the capture
+    with torch.no_grad():
+        getattr(net.unet.out, "2").bias.add_(1.0)
+    net.use_graph = True
+    shifted = net(xa)
+    assert torch.allclose(shifted, ea + 1.0, atol=1e-5) and len(net._graphs) == 1
+
+
+@pytest.mark.parametrize("C,D", [(768, 12), (64, 16), (48, 9)])
+def test_fused_voxel_grid_path(hip_device, C, D):
+    """(D, H, W, C) float16 voxel grid -> both networks, with the first projector convolution of both networks fused into
+    one read of the grid (pixie_projector_conv0), against (a) the operator: an fp64 F.conv3d of the float32-converted grid,
+    and (b) the whole pipeline: oracle/unet_oracle.py on the float32 NCDHW tensor the reference's loader would build
+    (my_data.py:160-224).  C = 768 is the shipped feature width (config/training/default.yaml:5,29)."""
+    from pixie_amd.unet import HipOps, RegressionUNet, SegmentationUNet, predict_material_field, predict_material_field_from_voxel_grid
+    from pixie_amd.voxel_grid import load_voxel_grid
+    rng = np.random.default_rng(C + D)
+    grid = rng.normal(size=(D, D, D, C)).astype(np.float16)
+    grid *= (rng.random((D, D, D, 1)) < 0.7)                                   # empty voxels, as real grids have
+    kw = dict(feature_channels=C, cond_dim=32, model_channels=32, num_res_blocks=1, channel_mult=(1, 2), attention_resolutions=(), grid_size=D)
+    seg, cont = SegmentationUNet(num_classes=8, **kw), RegressionUNet(out_channels=3, **kw)
+    sd_s, sd_c = synthetic_state_dict(seg.cfg, 21), synthetic_state_dict(cont.cfg, 22)
+    seg.load_numpy_state(sd_s); cont.load_numpy_state(sd_c)
+    seg, cont = seg.to(hip_device).eval(), cont.to(hip_device).eval()
+    g_dev = torch.from_numpy(grid).to(hip_device)
+    # (a) the operator
+    ops = HipOps(hip_device)
+    outs = ops.projector_conv0(g_dev, [(ops.pack_conv16(seg.projector.net._modules["0"].weight), seg.projector.net._modules["0"].bias),
+                                       (ops.pack_conv16(cont.projector.net._modules["0"].weight), cont.projector.net._modules["0"].bias)], 128)
+    x64 = torch.from_numpy(grid.astype(np.float64)).permute(3, 0, 1, 2)[None]
+    for out, sd in zip(outs, (sd_s, sd_c)):
+        ref = F.conv3d(x64, torch.from_numpy(sd["projector.net.0.weight"]).double(), torch.from_numpy(sd["projector.net.0.bias"]).double())[0]
+        assert rel_l2(out.cpu().numpy(), ref.numpy()) < 5e-7                       # exact fp16 inputs x 22-bit weights
+    # a single network (the other tiling of the kernel)
+    one = ops.projector_conv0(g_dev, [(ops.pack_conv16(seg.projector.net._modules["0"].weight), seg.projector.net._modules["0"].bias)], 128)[0]
+    assert torch.equal(one, outs[0])
+    # (b) the whole pipeline
+    combined, seg_pred, logits, cpred = predict_material_field_from_voxel_grid(seg, cont, g_dev)
+    feat32 = grid.astype(np.float32).transpose(3, 0, 1, 2)[None]
+    e1 = rel_l2(logits.cpu().numpy(), unet_oracle.unet_forward(sd_s, seg.cfg, feat32).numpy())
+    e2 = rel_l2(cpred.cpu().numpy(), unet_oracle.unet_forward(sd_c, cont.cfg, feat32).numpy())
+    print(f"fused grid path C={C} D={D}: logits {e1:.2e}, regression {e2:.2e}")
+    assert e1 < 1e-4 and e2 < 1e-4
+    # and it agrees with the unfused route (loader kernel + the networks' own first conv)
+    c2, s2, l2, p2 = predict_material_field(seg, cont, load_voxel_grid(grid, hip_device))
+    assert rel_l2(logits.cpu().numpy(), l2.cpu().numpy()) < 2e-5 and float((seg_pred == s2).float().mean()) > 0.999
+    assert combined.shape == (1, 11, D, D, D)
+
+
 def test_cpu_tensors_are_rejected(hip_device):
     from pixie_amd._lib import PixieHipError
     from pixie_amd.unet import RegressionUNet
