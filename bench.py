@@ -162,8 +162,8 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     precision = seg.conv_precision
     feat = torch.from_numpy(feature_grid(D, C, seed=100 + rank)).to(device)  # scene i uses seed 100+i
 
-    def step():
-        combined, seg_pred, _, cont_pred = predict_material_field(seg, cont, feat)
+    def step(dual_stream=None):
+        combined, seg_pred, _, cont_pred = predict_material_field(seg, cont, feat, dual_stream=dual_stream)
         if world > 1:
             pd.all_gather_fields(cont_pred, seg_pred)
         return combined
@@ -171,7 +171,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     for _ in range(n_warm):
         step()
     prof = ConvProfiler()
-    prof.wrap(seg._runner.ops)   # both networks share one HipOps instance per device? no: wrap both
+    prof.wrap(seg._runner.ops)   # one HipOps instance per network
     if cont._runner.ops is not seg._runner.ops:
         prof.wrap(cont._runner.ops)
     barrier_sync(world)
@@ -181,7 +181,15 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, device)
     flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
-    # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution)
+    # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution).  In the timed region the
+    # two networks run on two HIP streams, so an event pair around one network's launch also brackets whatever the other
+    # network had on the device: those durations are kept (`avg_launch_ms_in_timed_region`), and the launch duration the
+    # roofline is computed from comes from two more scenes run on ONE stream right after the timed region.
+    agg_timed = prof.summary()
+    kernel_avg_timed = prof.by_variant()
+    prof.records.clear(); prof.variants.clear()
+    for _ in range(2):
+        step(dual_stream=False)
     agg = prof.summary()
     dom_key = (64, 64, 3, 1, False, (D, D, D))
     roof = None
@@ -197,6 +205,8 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
                     "traffic": (load_traffic().get("conv_64_64_128") or {}).get("hbm_bytes_per_launch"),
                     "traffic_source": "profiles/pmc_traffic.json" if load_traffic().get("conv_64_64_128") else None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl,
+                    "avg_launch_ms_in_timed_region": (round(agg_timed[dom_key][0] / agg_timed[dom_key][1], 4) if dom_key in agg_timed else None),
+                    "launch_timing": "HIP events on the launch stream; single-stream pass of 2 scenes after the timed region (see bench.py)",
                     "mfma_issue_ratio": 3, "mfma_hw_tflops": round(3 * ach, 1), "mfma_hw_frac": round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
                     "vs_exact_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
                     # scripts/microbench/mfma_lds.hip: this kernel's tap loop, bare, on random fp16 operands (the nominal peak
@@ -209,10 +219,10 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
             roof = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,2,4,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
-    conv_ms = sum(v[0] for v in agg.values()) / max(n_steps, 1)
+    conv_ms = sum(v[0] for v in agg.values()) / 2.0
     return dict(seconds=dt, steps=n_steps, voxels=world * n_steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision,
-                conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / max(n_steps, 1), 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
-                kernel_avg=prof.by_variant())
+                conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / 2.0, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
+                kernel_avg=prof.by_variant(), kernel_avg_timed=kernel_avg_timed)
 
 
 def bench_shipped_shape(args, device):
@@ -515,7 +525,8 @@ def main():
                 line["mpm_1m"]["cpu_baseline"] = cpu["mpm_1m"]
         line["layer_ms_top"] = u["layer_ms"]
         # per kernel NAME, all shapes pooled: comparable with the avg column of profiles/*_kernel_stats.csv (rocprofv3 --stats)
-        line["conv_kernel_avg_ms"] = u["kernel_avg"]
+        line["conv_kernel_avg_ms"] = u["kernel_avg"]                           # single-stream pass
+        line["conv_kernel_avg_ms_in_timed_region"] = u["kernel_avg_timed"]    # two streams: launches of the two networks overlap
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

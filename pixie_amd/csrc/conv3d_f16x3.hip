@@ -857,6 +857,7 @@ static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStr
     return 0;
 }
 
+static int g_conv_force_nb = 0;   // timing experiments (pixie_set_option "conv_force_nb"): 1, 2 or 4 voxel blocks per wave; 0 = heuristic
 // geometry + tile selection shared by the launcher, pixie_conv_stats_floats and pixie_stats_finalize
 static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, int& NB_out, int* slices_out = nullptr) {
     a.ID = d->in_d; a.IH = d->in_h; a.IW = d->in_w;
@@ -894,6 +895,7 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
         if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
     }
     if (slices_out) *slices_out = slices;
+    if (g_conv_force_nb > 0 && slices == 1 && a.stride == 1) NB = g_conv_force_nb;
 
     const int tile_vox = 128 * NB;
     a.TX = pow2_le16(a.OW, 32);
@@ -1028,6 +1030,7 @@ extern "C" int pixie_set_option(const char* key, int value) {
     PX_REQUIRE(key, "pixie_set_option: null key");
     if (std::string(key) == "conv_pipeline") { conv_set_pipe(value != 0); return 0; }
     if (std::string(key) == "conv_dbg") { g_conv_dbg = value; return 0; }
+    if (std::string(key) == "conv_force_nb") { PX_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "conv_force_nb: 0, 1, 2 or 4"); g_conv_force_nb = value; return 0; }
     if (std::string(key) == "conv_wave_specialised") { g_conv_ws = value != 0; return 0; }
     return set_error("pixie_set_option: unknown key '%s'", key);
 }

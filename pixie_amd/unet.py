@@ -566,10 +566,15 @@ def _side_streams(device):
 
 
 @torch.no_grad()
-def predict_material_field(seg_network: SegmentationUNet, cont_network: RegressionUNet, feat_grid: torch.Tensor):
+def predict_material_field(seg_network: SegmentationUNet, cont_network: RegressionUNet, feat_grid: torch.Tensor,
+                           dual_stream: Optional[bool] = None):
     """The compute of process_batch + save_predictions (trainer/inference_combined.py:122-126,186-195):
-    returns (combined (N, 3+num_classes, D, H, W), seg_pred (N, D, H, W) int32, seg_logits, cont_pred)."""
-    if os.environ.get("PIXIE_DUAL_STREAM", "0") == "1" and feat_grid.is_cuda:
+    returns (combined (N, 3+num_classes, D, H, W), seg_pred (N, D, H, W) int32, seg_logits, cont_pred).
+    `dual_stream` (default: on, PIXIE_DUAL_STREAM=0 turns it off): the two networks run on two HIP streams (measured
+    94.7 -> 89.6 ms per 128^3 scene)."""
+    if dual_stream is None:
+        dual_stream = os.environ.get("PIXIE_DUAL_STREAM", "1") == "1"
+    if dual_stream and feat_grid.is_cuda:
         # the two networks are independent: run them on two HIP streams so that one network's small kernels and
         # kernel tails fill the CUs the other leaves idle
         cur = torch.cuda.current_stream()

@@ -283,6 +283,44 @@ def test_rollout_parity_config3(hip_device):
     assert abs(h.time - 1000 * sc["dt"]) < 1e-9
 
 
+@pytest.mark.parametrize("material", ["sand", "snow", "metal"])
+def test_plastic_reference_configs_100k(hip_device, material):
+    """The reference's own plastic configurations (PG/config/objaverse/custom_{sand,snow,metal}_config.json: parameters,
+    n_grid 200 / 120, substep 2e-5 / 1e-5, gravity, damping, boundary conditions) with 100 000 particles for 200 substeps,
+    against the float64 C oracle's committed trajectory (tests/golden/make_mpm_plastic_golden.py, which perturbs the initial
+    F and v so that the return mappings work from the first substep).  Bar: x and F <= 1e-4 outright; v (on the scale of
+    rms|v|) and the yield stress <= max(1e-4, 4 x the float32 oracle's own drift)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_mpm_plastic_golden import plastic_scene, start
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"mpm_plastic_{material}.npz"))
+    n, stride = int(g["n"]), int(g["stride"])
+    sc = plastic_scene(material)
+    from pixie_amd.mpm_solver import MPM_Simulator_WARP
+    h = MPM_Simulator_WARP(10)
+    h.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
+                                   n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
+    start(h, sc, lambda f, a: h.set_field(f, a.reshape(n, -1)))
+    done = 0
+    for cp in [int(c) for c in g["checkpoints"]]:
+        h.run(sc["dt"], cp - done); done = cp
+        d_x, d_disp, d_v, d_F, d_ys = (float(t) for t in g[f"drift_{cp}"])
+        x, v, F, ys = (get(h, f).astype(np.float64) for f in ("x", "v", "F", "yield_stress"))
+        F = F.reshape(-1, 3, 3)
+        e_x, e_F = rel_l2(x[::stride], g[f"x_{cp}"]), rel_l2(F[::stride], g[f"F_{cp}"])
+        e_v = rel_l2(v[::stride], g[f"v_{cp}"])
+        e_ys = rel_l2(ys[::stride], g[f"yield_stress_{cp}"]) if material != "sand" else 0.0
+        print(f"{material} @ substep {cp}: x {e_x:.2e} (f32 oracle {d_x:.2e}), F {e_F:.2e} ({d_F:.2e}), v {e_v:.2e} ({d_v:.2e}), "
+              f"yield stress {e_ys:.2e} ({d_ys:.2e})")
+        assert np.isfinite(x).all() and np.isfinite(F).all()
+        assert e_x < 1e-4 and e_F < 1e-4
+        assert e_v < max(1e-4, 4 * d_v) and e_ys < max(1e-4, 4 * d_ys)
+    print(f"{material}: {100 * float(g['yielded_fraction']):.0f} % of the particles yielded within the 200 substeps")
+    assert float(g["yielded_fraction"]) > 0.05                    # the return mapping is really at work in this scene
+    assert h.out_of_bounds == 0 and int(g["oob"]) == 0
+
+
 def test_boundary_conditions_and_modifiers(hip_device):
     sc = mpm_ball_scene(8000, seed=8, scenario="ball")
     sc["params"] = dict(material="jelly", g=[0.0, 0.0, -2.0], E=5e4, nu=0.3, density=500.0, rpic_damping=0.1, grid_v_damping_scale=0.999)

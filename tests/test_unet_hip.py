@@ -405,10 +405,11 @@ def test_predict_material_field_and_batch(hip_device):
 
 
 def test_full_size_network_two_independent_executions_agree(hip_device):
-    """BASELINE config 2 (128^3 x 64, both networks, 27 TFLOP): no CPU oracle finishes at this size, so the same
-    networks are executed twice on the device by two independent kernel families -- the f16x3 path (split-fp16 MFMA,
-    fused statistics, split-K) and the exact-fp32 MFMA path (separate statistics passes) -- and must agree; plus the
-    properties of the combined field (finite, exactly one class per voxel, argmax of the logits)."""
+    """BASELINE config 2 (128^3 x 64, both networks, 27 TFLOP) executed twice on the device by two independent kernel
+    families -- the f16x3 path (split-fp16 MFMA, fused statistics, split-K) and the exact-fp32 MFMA path (separate
+    statistics passes) -- on a second input: a cross-check ON TOP of test_network_matches_reference_at_north_star_size
+    (which holds both paths to the reference's own 128^3 outputs); plus the properties of the combined field (finite,
+    exactly one class per voxel, argmax of the logits)."""
     from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
     D = 128
     kw = dict(feature_channels=64, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4),
