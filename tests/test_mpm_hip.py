@@ -357,6 +357,45 @@ def test_boundary_conditions_and_modifiers(hip_device):
     assert err < max(1e-3, 2 * drift)
 
 
+def test_regrid_after_load_keeps_everything_but_the_grid(hip_device):
+    """set_parameters_dict(n_grid=...) AFTER the particles were loaded (mpm_solver_warp.py:315-342 re-allocates the three grid
+    arrays and recomputes dx, nothing else): material, gravity, model scalars, boundary conditions, particle modifiers and the
+    time must survive (the first implementation re-created the handle and lost them)."""
+    sc = mpm_ball_scene(6000, seed=3, scenario="ball", n_grid=40)
+    sc["params"] = dict(material="sand", g=[0.0, 0.0, -9.8], E=1e5, nu=0.3, density=1000.0, friction_angle=35.0, rpic_damping=0.05,
+                        grid_v_damping_scale=0.999)
+    sc["bcs"] = [dict(type="bounding_box"),
+                 dict(type="surface_collider", point=[1.0, 1.0, 0.6], normal=[0.0, 0.0, 1.0], surface="sticky", friction=0.0, start_time=0.0, end_time=1e3),
+                 dict(type="particle_impulse", force=[0.0, 0.05, 0.0], num_dt=5, start_time=0.0)]
+    h = make_hip(sc, per_particle=False)
+    h.run(sc["dt"], 5)                                   # time advances, the impulse window is half used
+    h.set_parameters_dict({"n_grid": 50})                # same material, scalars, BCs; finer grid
+    assert h.n_grid == 50 and abs(h._get_scalar("dx") - np.float32(2.0 / 50)) < 1e-9 and abs(h.time - 5 * sc["dt"]) < 1e-12
+    assert int(get(h, "material")[0]) == 2 and abs(h._get_scalar("rpic_damping") - np.float32(0.05)) < 1e-9
+    # the oracle: the same 5 substeps on the 40-grid, its particle state moved onto a 50-grid solver set up the same way
+    # (float64 as the yardstick, float32 for the rounding floor of this nearly stress-free sand ball in free fall)
+    res = {}
+    for prec in ("f64", "f32"):
+        o40 = make_oracle(sc, prec, per_particle=False)
+        o40.run(sc["dt"], 5)
+        sc50 = dict(sc); sc50["n_grid"] = 50
+        o50 = make_oracle(sc50, prec, per_particle=False)
+        for f in ("x", "v", "C", "F", "F_trial"):
+            o50.field(f)[:] = o40.field(f)
+        o50._lib.mpm_set_scalar(o50._h, b"time", float(o40.time))
+        o50.run(sc["dt"], 25)
+        res[prec] = {f: np.array(o50.field(f), np.float64) for f in ("x", "v", "F")}
+    h.run(sc["dt"], 25)
+    assert rel_l2(get(h, "x"), res["f64"]["x"]) < 1e-5
+    assert rel_l2(get(h, "F").reshape(-1, 3, 3), res["f64"]["F"]) < 1e-4
+    v_rms = float(np.linalg.norm(res["f64"]["v"]) / np.sqrt(6000))
+    err = float(np.linalg.norm(get(h, "v") - res["f64"]["v"]) / np.sqrt(6000)) / v_rms
+    drift = float(np.linalg.norm(res["f32"]["v"] - res["f64"]["v"]) / np.sqrt(6000)) / v_rms
+    print(f"regrid: v hip-vs-f64 {err:.2e}, oracle f32-vs-f64 {drift:.2e}")
+    assert err < max(1e-4, 4 * drift)
+    assert h.out_of_bounds == 0
+
+
 def test_exports_cov_and_rotation(hip_device):
     sc = mpm_ball_scene(5000, seed=9, scenario="ball")
     h, o = make_hip(sc), make_oracle(sc, "f32")
