@@ -259,6 +259,42 @@ int pixie_combine_predictions(const float* d_logits, int num_classes, const floa
 int pixie_combine_class_ids(const int32_t* d_seg_pred, int num_classes, const float* d_cont, int64_t spatial, float* d_combined,
                             void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * (A') One network as a handle -- what the reference does with an nn.Module: construction (MyUNetModel.__init__,
+ *      diffusion_network.py:712-873, FeatureProjector :534-589, behind SegmentationUNet / RegressionUNet,
+ *      trainer/training_discrete.py:50-88, trainer/training_continuous_mse.py:48-89), load_state_dict and
+ *      forward (:875-935) -- so that a scene costs ONE foreign call per network instead of ~400 operator calls.
+ *      The launch sequence equals pixie_amd/unet.py: UNetRunner.forward (bit-identical results); it allocates
+ *      nothing and never synchronises once the weights are packed, i.e. it can be captured into a HIP graph.
+ * -------------------------------------------------------------------------------------- */
+typedef struct pixie_unet pixie_unet;
+typedef struct pixie_unet_config {          /* the constructor arguments of the two wrappers */
+    int32_t feature_channels, cond_dim, model_channels, num_res_blocks;
+    int32_t n_channel_mult; int32_t channel_mult[8];
+    int32_t n_attention_resolutions; int32_t attention_resolutions[8];
+    int32_t grid_size;                      /* D = H = W of the feature grid (the LayerNorm([D,H,W]) parameters have this shape) */
+    int32_t out_channels;                   /* num_classes (segmentation) or 3 (regression) */
+    int32_t precision;                      /* 0: f16x3 convolutions where the shapes allow (default path), 1: exact fp32 MFMA everywhere */
+} pixie_unet_config;
+
+int pixie_unet_create(pixie_unet** out, const pixie_unet_config* cfg);
+int pixie_unet_destroy(pixie_unet* h);
+/* The state_dict: keys in the reference's registration order (a reference checkpoint loads key by key). */
+int pixie_unet_param_count(const pixie_unet* h);
+int pixie_unet_param_info(const pixie_unet* h, int index, const char** key, int64_t* numel, int32_t* ndim, int64_t shape[5]);
+/* Point parameter `key` at `numel` float32 values in device memory.  The memory stays the caller's and must outlive the
+ * handle's use of it; call again after changing the values (conv weights are re-packed, normalisation bounds re-taken, on
+ * the next forward).  An unknown key or a wrong size is an error, as with load_state_dict(strict=True). */
+int pixie_unet_set_param(pixie_unet* h, const char* key, const float* d_values, int64_t numel);
+/* Bytes of device scratch one forward pass over a (d, h, w) grid needs (all activations, statistics and split-K buffers). */
+int64_t pixie_unet_workspace_bytes(pixie_unet* h, int d, int hh, int w);
+/* forward: d_feat (feature_channels, d, h, w) float32 -> d_out (out_channels, d, h, w) float32, all launches on `stream`.
+ * d_proj0 (optional, hidden-128 projector only): the output of projector.net[0] computed elsewhere (pixie_projector_conv0 on
+ * the channels-last grid); d_feat may then be NULL.  The first call after pixie_unet_set_param packs weights (hipMalloc) and
+ * synchronises the stream once to read the normalisation bounds; later calls are launch-only. */
+int pixie_unet_forward(pixie_unet* h, const float* d_feat, const float* d_proj0, int d, int hh, int w, float* d_out,
+                       void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* ======================================================================================
  * (C) Field -> particle transfer between the two halves: replaces the PLY round trip
  *     pixie/voxel/map_pred_to_coords.py:41-75,192-252 (unscale_prediction + masked voxel point list) and

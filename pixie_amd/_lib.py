@@ -53,6 +53,14 @@ class ConvDesc(C.Structure):
                 ("out_d", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32)]
 
 
+class UNetConfigC(C.Structure):
+    """struct pixie_unet_config"""
+    _fields_ = [("feature_channels", C.c_int32), ("cond_dim", C.c_int32), ("model_channels", C.c_int32), ("num_res_blocks", C.c_int32),
+                ("n_channel_mult", C.c_int32), ("channel_mult", C.c_int32 * 8),
+                ("n_attention_resolutions", C.c_int32), ("attention_resolutions", C.c_int32 * 8),
+                ("grid_size", C.c_int32), ("out_channels", C.c_int32), ("precision", C.c_int32)]
+
+
 class FieldDesc(C.Structure):
     """struct pixie_field_desc"""
     _fields_ = [("d_pred", C.c_void_p), ("d_mask", C.c_void_p),
@@ -106,6 +114,13 @@ SIGNATURES = {
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
     "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
     "pixie_projector_conv0": (_I, [_VP, _I64, _I, _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _I, _VP]),
+    "pixie_unet_create": (_I, [C.POINTER(_VP), C.POINTER(UNetConfigC)]),
+    "pixie_unet_destroy": (_I, [_VP]),
+    "pixie_unet_param_count": (_I, [_VP]),
+    "pixie_unet_param_info": (_I, [_VP, _I, C.POINTER(_S), C.POINTER(_I64), C.POINTER(C.c_int32), C.POINTER(_I64)]),
+    "pixie_unet_set_param": (_I, [_VP, _S, _VP, _I64]),
+    "pixie_unet_workspace_bytes": (_I64, [_VP, _I, _I, _I]),
+    "pixie_unet_forward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _I64, _VP]),
     "pixie_combine_class_ids": (_I, [_VP, _I, _VP, _I64, _VP, _VP]),
     "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),
     "pixie_voxel_grid_to_ncdhw": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

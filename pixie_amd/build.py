@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpixie_hip.so")
 ARCH = "gfx950"
-SOURCES = ["common.hip", "mpm.hip", "unet_ops.hip", "conv3d_mfma.hip", "conv3d_f16x3.hip", "projector_fused.hip", "field_transfer.hip", "particle_filling.hip"]
+SOURCES = ["common.hip", "mpm.hip", "unet_ops.hip", "conv3d_mfma.hip", "conv3d_f16x3.hip", "unet_exec.hip", "projector_fused.hip", "field_transfer.hip", "particle_filling.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
 # Per-file flags.  mpm.hip: hipcc's SLP vectoriser turns a third of the fused MPM kernel's fp32 arithmetic into packed

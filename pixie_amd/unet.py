@@ -421,6 +421,72 @@ class UNetRunner:
                           bound=self._norm_bound("unet.out.0", h[0].numel()))
 
 
+class UNetHandle:
+    """One network behind the C handle of include/pixie_hip.h section (A'): pixie_unet_create / set_param / forward.  The
+    whole forward pass is ONE foreign call; the plan walk, the temporaries (one workspace tensor) and the ~400 launches are
+    the library's (csrc/unet_exec.hip).  Bit-identical to UNetRunner + HipOps, which it replaces as the default executor."""
+
+    def __init__(self, cfg: UNetConfig, precision: str, device: torch.device):
+        if device.type != "cuda":
+            raise _lib.PixieHipError("pixie_amd U-Net runs on a HIP device only (no CPU fallback)")
+        if precision not in ("f16x3", "f32"):
+            raise ValueError(f"unknown conv precision {precision!r}")
+        self.lib = _lib.load()
+        self.cfg, self.precision, self.device = cfg, precision, device
+        c = _lib.UNetConfigC()
+        c.feature_channels, c.cond_dim, c.model_channels, c.num_res_blocks = cfg.feature_channels, cfg.cond_dim, cfg.model_channels, cfg.num_res_blocks
+        c.n_channel_mult = len(cfg.channel_mult)
+        for i, m in enumerate(cfg.channel_mult):
+            c.channel_mult[i] = int(m)
+        c.n_attention_resolutions = len(cfg.attention_resolutions)
+        for i, m in enumerate(cfg.attention_resolutions):
+            c.attention_resolutions[i] = int(m)
+        c.grid_size, c.out_channels, c.precision = cfg.grid_size, cfg.out_channels, 0 if precision == "f16x3" else 1
+        self._h = C.c_void_p()
+        check(self.lib.pixie_unet_create(C.byref(self._h), C.byref(c)), "pixie_unet_create")
+        weakref.finalize(self, self.lib.pixie_unet_destroy, self._h)
+        self._seen: Dict[str, Tuple[int, int]] = {}
+        self._keep: Dict[str, torch.Tensor] = {}      # the tensors the handle points at stay alive here
+
+    def keys(self) -> List[str]:
+        out = []
+        for i in range(self.lib.pixie_unet_param_count(self._h)):
+            key = C.c_char_p()
+            check(self.lib.pixie_unet_param_info(self._h, i, C.byref(key), None, None, None), "pixie_unet_param_info")
+            out.append(key.value.decode())
+        return out
+
+    def load(self, params: Dict[str, torch.Tensor]) -> None:
+        """load_state_dict: hand every parameter that changed since the last call (by storage and version) to the handle."""
+        for key, t in params.items():
+            tag = (t.data_ptr(), t._version)
+            if self._seen.get(key) == tag:
+                continue
+            v = t.detach()
+            if v.device != self.device or v.dtype != torch.float32 or not v.is_contiguous():
+                v = v.to(self.device, torch.float32).contiguous()
+            self._keep[key] = v
+            check(self.lib.pixie_unet_set_param(self._h, key.encode(), _ptr(v), v.numel()), "pixie_unet_set_param")
+            self._seen[key] = tag
+
+    def workspace_bytes(self, d: int, h: int, w: int) -> int:
+        n = int(self.lib.pixie_unet_workspace_bytes(self._h, d, h, w))
+        if n < 0:
+            raise _lib.PixieHipError(self.lib.pixie_last_error().decode())
+        return n
+
+    def forward(self, feat: Optional[torch.Tensor], proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat (C_feat, D, H, W) float32 (or None with proj0 = the output of projector.net[0]) -> (out_channels, D, H, W)."""
+        src = proj0 if proj0 is not None else feat
+        d, h, w = (int(v) for v in src.shape[1:])
+        out = torch.empty((self.cfg.out_channels, d, h, w), device=self.device, dtype=torch.float32)
+        nbytes = self.workspace_bytes(d, h, w)
+        workspace = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        check(self.lib.pixie_unet_forward(self._h, _ptr(feat), _ptr(proj0), d, h, w, _ptr(out), _ptr(workspace), nbytes,
+                                          _lib.current_stream_ptr()), "pixie_unet_forward")
+        return out
+
+
 class _Node(nn.Module):
     """Empty container used to reproduce the reference's state_dict key hierarchy."""
 
@@ -440,6 +506,10 @@ class _PixieUNet(nn.Module):
                 node = node._modules[name]
             node.register_parameter(parts[-1], nn.Parameter(self._init(key, shape, shapes, gen), requires_grad=False))
         self._runner: Optional[UNetRunner] = None
+        self._handle: Optional[UNetHandle] = None
+        # "c" (default): the whole pass is one call into the library's own executor (pixie_unet_forward);
+        # "python": this file walks the plan and calls one operator at a time (the same launches; needed for `taps`)
+        self.executor = os.environ.get("PIXIE_UNET_EXECUTOR", "c")
         self.conv_precision = DEFAULT_PRECISION  # "f16x3" (default) or "f32" (exact-fp32 MFMA everywhere)
         self.use_graph = os.environ.get("PIXIE_UNET_GRAPH", "0") == "1"   # replay a captured HIP graph per (shape, weights)
         self._graphs: Dict[tuple, tuple] = {}
@@ -471,15 +541,31 @@ class _PixieUNet(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda" or feat_grid.device != dev:
             raise _lib.PixieHipError("model and input must live on the same HIP device (no CPU fallback)")
-        if self._runner is None or self._runner.ops.device != dev or self._runner.precision != self.conv_precision:
-            self._runner = UNetRunner(self.cfg, self._params(), HipOps(dev), precision=self.conv_precision)
-        else:
-            self._runner.p = self._params()
+        self._prepare(dev)
         x = feat_grid.detach().to(torch.float32).contiguous()
         if self.use_graph and taps is None:
             return torch.stack([self._forward_graphed(x[n]) for n in range(x.shape[0])], dim=0)
-        outs = [self._runner.forward(x[n], taps if n == 0 else None) for n in range(x.shape[0])]
+        outs = [self._forward_one(x[n], taps=taps if n == 0 else None) for n in range(x.shape[0])]
         return torch.stack(outs, dim=0)
+
+    def _prepare(self, dev) -> None:
+        """(Re)bind the executors to the current parameters, device and precision."""
+        params = self._params()
+        if self._runner is None or self._runner.ops.device != dev or self._runner.precision != self.conv_precision:
+            self._runner = UNetRunner(self.cfg, params, HipOps(dev), precision=self.conv_precision)
+        else:
+            self._runner.p = params
+        if self.executor == "c":
+            if self._handle is None or self._handle.device != dev or self._handle.precision != self.conv_precision:
+                self._handle = UNetHandle(self.cfg, self.conv_precision, dev)
+            self._handle.load(params)
+        elif self.executor != "python":
+            raise ValueError(f"unknown executor {self.executor!r} (PIXIE_UNET_EXECUTOR is 'c' or 'python')")
+
+    def _forward_one(self, x: Optional[torch.Tensor], taps: Optional[dict] = None, proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.executor == "c" and taps is None:
+            return self._handle.forward(x, proj0)
+        return self._runner.forward(x, taps, proj0)
 
     def _forward_graphed(self, x: torch.Tensor) -> torch.Tensor:
         """One sample through a captured HIP graph.  A forward pass is ~400 kernel launches driven from Python (ctypes) with
@@ -491,16 +577,16 @@ class _PixieUNet(nn.Module):
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs.clear()                       # a new shape / parameter version invalidates the old capture
-            self._runner.forward(x)                    # eager warm-up: weight packing, bounds, function attributes
+            self._forward_one(x)                       # eager warm-up: weight packing, bounds, function attributes
             static_in = x.clone()
             side = torch.cuda.Stream(x.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # capture must not run on the legacy default stream
-                self._runner.forward(static_in)
+                self._forward_one(static_in)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = self._runner.forward(static_in)
+                static_out = self._forward_one(static_in)
             ent = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = ent
         static_in.copy_(x)
@@ -527,7 +613,8 @@ class RegressionUNet(_PixieUNet):
 
 
 @torch.no_grad()
-def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont_network: "RegressionUNet", grid_dhwc_f16: torch.Tensor):
+def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont_network: "RegressionUNet", grid_dhwc_f16: torch.Tensor,
+                                           dual_stream: Optional[bool] = None):
     """The same as predict_material_field, fed with the voxel grid as the reference stores it -- (D, H, W, C) float16,
     `clip_features_features.npy` (pixie/voxel/voxelize.py:86,111) -- instead of the float32 (1, C, D, H, W) tensor
     my_data.py:160-224 makes of it.  The first projector convolution of BOTH networks reads the grid once
@@ -541,16 +628,27 @@ def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont
     for net in nets:
         if net.cfg.projector_hidden is None or net.cfg.feature_channels != g.shape[3] or net.conv_precision != "f16x3":
             raise ValueError("the fused grid path needs the hidden-128 projector, matching feature_channels and conv_precision 'f16x3'")
-        if net._runner is None or net._runner.ops.device != dev or net._runner.precision != net.conv_precision:
-            net._runner = UNetRunner(net.cfg, net._params(), HipOps(dev), precision=net.conv_precision)
-        else:
-            net._runner.p = net._params()
+        net._prepare(dev)
     ops = seg_network._runner.ops
     q = "projector.net.0"
     packed = [(net._runner._w16(q), net._runner._b(q)) for net in nets]
     x_seg, x_cont = ops.projector_conv0(g, packed, seg_network.cfg.projector_hidden)
-    seg_logits = seg_network._runner.forward(None, proj0=x_seg)[None]
-    cont_pred = cont_network._runner.forward(None, proj0=x_cont)[None]
+    if dual_stream is None:
+        dual_stream = os.environ.get("PIXIE_DUAL_STREAM", "1") == "1"
+    if dual_stream:   # as in predict_material_field: the two networks on two HIP streams behind the shared first convolution
+        cur = torch.cuda.current_stream()
+        s1, s2 = _side_streams(dev)
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            seg_logits = seg_network._forward_one(None, proj0=x_seg)[None]
+        with torch.cuda.stream(s2):
+            cont_pred = cont_network._forward_one(None, proj0=x_cont)[None]
+        x_seg.record_stream(s1); x_cont.record_stream(s2)
+        cur.wait_stream(s1); cur.wait_stream(s2)
+        seg_logits.record_stream(cur); cont_pred.record_stream(cur)
+    else:
+        seg_logits = seg_network._forward_one(None, proj0=x_seg)[None]
+        cont_pred = cont_network._forward_one(None, proj0=x_cont)[None]
     combined, seg_pred = ops.combine(seg_logits[0].contiguous(), cont_pred[0].contiguous())
     return combined[None], seg_pred[None], seg_logits, cont_pred
 

@@ -4,5 +4,5 @@ TAG=${1:-t}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1500 python -m pytest $2 -m gpu -q --tb=short -p no:cacheprovider > $OUT/pytest.log 2>&1
+eval timeout 1500 python -m pytest "$2" -m gpu -q --tb=short -p no:cacheprovider > $OUT/pytest.log 2>&1
 tail -25 $OUT/pytest.log

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(tmp_path):
     """sizeof/offsetof of every struct field, as gcc lays out include/pixie_hip.h, equal the ctypes mirrors."""
     import subprocess
     structs = {"pixie_bc_desc": _lib.BCDesc, "pixie_pmod_desc": _lib.PModDesc, "pixie_conv_desc": _lib.ConvDesc,
-               "pixie_field_desc": _lib.FieldDesc}
+               "pixie_field_desc": _lib.FieldDesc, "pixie_unet_config": _lib.UNetConfigC}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "pixie_hip.h")}"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

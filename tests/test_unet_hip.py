@@ -370,7 +370,10 @@ def test_network_matches_reference_golden(hip_device, name, precision):
         model = model.to(hip_device).eval()
         model.conv_precision = precision
         taps = {}
-        y = model(feat, taps).cpu().numpy()
+        y = model(feat, taps).cpu().numpy()        # `taps` selects the Python plan walk (one foreign call per operator)
+        assert model.executor == "c"
+        y_handle = model(feat).cpu().numpy()       # the product default: pixie_unet_forward, one foreign call per network
+        assert np.array_equal(y_handle, y), f"{name}/{head}/{precision}: the C executor and the Python plan walk differ"
         err = rel_l2(y, g[head])
         print(f"{name}/{head}/{precision}: rel-L2 vs reference golden {err:.3e}")
         if err >= 1e-4:  # localise the first diverging layer
@@ -384,6 +387,53 @@ def test_network_matches_reference_golden(hip_device, name, precision):
             agree = float((y.argmax(1) == g[head].argmax(1)).mean())
             print(f"{name}: rel-L2 {err:.2e}, argmax agreement {agree:.6f}")
             assert agree > 0.999
+
+
+def test_unet_handle_follows_parameter_updates_and_rejects_bad_calls(hip_device):
+    """pixie_unet_set_param after the first pass: re-packed weights and re-taken normalisation bounds (in-place parameter
+    edits bump the tensor version, as an optimiser step or load_state_dict does); errors of the handle API are loud."""
+    import ctypes as C
+    from pixie_amd import _lib
+    from pixie_amd.unet import RegressionUNet, UNetHandle
+    kw, wseed, iseed = CASES["full16"]
+    model = RegressionUNet(kw["feature_channels"], kw["cond_dim"], kw["model_channels"], kw["num_res_blocks"], kw["channel_mult"],
+                           kw["attention_resolutions"], kw["grid_size"], 3)
+    model.load_numpy_state(synthetic_state_dict(model.cfg, wseed))
+    model = model.to(hip_device).eval()
+    feat = torch.from_numpy(feature_grid(kw["grid_size"], kw["feature_channels"], seed=iseed)).to(hip_device)
+    y0 = model(feat)
+    with torch.no_grad():
+        model.unet.out._modules["2"].weight.mul_(2.0)                 # a conv weight
+        model.unet.out._modules["0"].weight.mul_(8.0)                 # a LayerNorm gamma: the f16x3 input bound must follow
+        first_res = model.unet.input_blocks._modules["1"]._modules["0"]
+        first_res.in_layers._modules["0"].bias.add_(0.5)
+    y1 = model(feat)
+    model.executor = "python"
+    y1_py = model(feat)
+    assert torch.equal(y1, y1_py) and not torch.equal(y0, y1)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = unet_oracle.unet_forward(sd, model.cfg, feat.cpu().numpy()).numpy()
+    assert rel_l2(y1.cpu().numpy(), ref) < 1e-4
+    # API errors
+    h = UNetHandle(model.cfg, "f16x3", hip_device)
+    assert h.keys() == list(model.state_dict().keys())
+    lib = _lib.load()
+    t = torch.zeros(7, device=hip_device)
+    assert lib.pixie_unet_set_param(h._h, b"unet.no_such_layer.weight", C.c_void_p(t.data_ptr()), 7) != 0
+    assert b"unexpected key" in lib.pixie_last_error()
+    assert lib.pixie_unet_set_param(h._h, b"unet.out.2.bias", C.c_void_p(t.data_ptr()), 7) != 0
+    with pytest.raises(_lib.PixieHipError, match="never set"):
+        h.forward(feat[0])
+    h.load({k: v for k, v in model.named_parameters()})
+    out = torch.empty((3,) + tuple(feat.shape[2:]), device=hip_device)
+    ws = torch.empty(1024, dtype=torch.uint8, device=hip_device)
+    rc = lib.pixie_unet_forward(h._h, C.c_void_p(feat.data_ptr()), None, 16, 16, 16, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), 1024,
+                                _lib.current_stream_ptr())
+    assert rc != 0 and b"workspace" in lib.pixie_last_error()
+    rc = lib.pixie_unet_forward(h._h, C.c_void_p(feat.data_ptr()), None, 8, 8, 8, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), 1024,
+                                _lib.current_stream_ptr())
+    assert rc != 0 and b"16^3" in lib.pixie_last_error()
+    assert torch.equal(h.forward(feat[0]), y1[0])
 
 
 def test_predict_material_field_and_batch(hip_device):
