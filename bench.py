@@ -111,7 +111,8 @@ class ConvProfiler:
             e1.record()
             cin = sum(int(p.shape[0]) for p in parts)
             o = out[0] if isinstance(out, tuple) else out   # (output, epilogue channel sums) on the fused-statistics path
-            prof.records.append(((cin, cout, ksize, kw.get("stride", 1), bool(kw.get("upsample", False)), tuple(o.shape[1:])), e0, e1))
+            folded = sum(int(t.shape[0]) for t in kw["skip"]["parts"]) if kw.get("skip") else 0   # input channels of a folded 1x1x1 skip conv
+            prof.records.append(((cin, cout, ksize, kw.get("stride", 1), bool(kw.get("upsample", False)), tuple(o.shape[1:]), folded), e0, e1))
             prof.variants.append(ops.last_variant)
             return out
 
@@ -170,10 +171,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
 
     for _ in range(n_warm):
         step()
-    prof = ConvProfiler()
-    prof.wrap(seg._runner.ops)   # one HipOps instance per network
-    if cont._runner.ops is not seg._runner.ops:
-        prof.wrap(cont._runner.ops)
+    executor = f"{seg.executor}{'+hip_graph' if seg.use_graph else ''}"
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(n_steps):
@@ -181,17 +179,28 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, device)
     flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
-    # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution).  In the timed region the
-    # two networks run on two HIP streams, so an event pair around one network's launch also brackets whatever the other
-    # network had on the device: those durations are kept (`avg_launch_ms_in_timed_region`), and the launch duration the
-    # roofline is computed from comes from two more scenes run on ONE stream right after the timed region.
+    # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution).  The timed region above is
+    # the product default: each network is ONE pixie_unet_forward call replayed as a captured HIP graph, the two networks on two
+    # HIP streams -- no per-launch events can be placed there.  The launch durations the roofline is computed from come from
+    # scenes run right after it through the Python plan walk (the same kernels, one foreign call per launch, HIP events around
+    # each): one scene on two streams (`avg_launch_ms_dual_stream`: an event pair around one network's launch also brackets
+    # whatever the other network had on the device) and two scenes on ONE stream (`avg_launch_ms`, the roofline's duration).
+    for net in (seg, cont):
+        net.executor, net.use_graph = "python", False
+    step(dual_stream=False)                      # the plan walk packs its own copy of the weights
+    prof = ConvProfiler()
+    prof.wrap(seg._runner.ops)   # one HipOps instance per network
+    if cont._runner.ops is not seg._runner.ops:
+        prof.wrap(cont._runner.ops)
+    step()
+    torch.cuda.synchronize()
     agg_timed = prof.summary()
     kernel_avg_timed = prof.by_variant()
     prof.records.clear(); prof.variants.clear()
     for _ in range(2):
         step(dual_stream=False)
     agg = prof.summary()
-    dom_key = (64, 64, 3, 1, False, (D, D, D))
+    dom_key = (64, 64, 3, 1, False, (D, D, D), 0)   # (c_in, c_out, ksize, stride, upsample, output dims, folded skip channels)
     roof = None
     if dom_key in agg:
         ms = agg[dom_key][0] / agg[dom_key][1]
@@ -205,8 +214,8 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
                     "traffic": (load_traffic().get("conv_64_64_128") or {}).get("hbm_bytes_per_launch"),
                     "traffic_source": "profiles/pmc_traffic.json" if load_traffic().get("conv_64_64_128") else None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl,
-                    "avg_launch_ms_in_timed_region": (round(agg_timed[dom_key][0] / agg_timed[dom_key][1], 4) if dom_key in agg_timed else None),
-                    "launch_timing": "HIP events on the launch stream; single-stream pass of 2 scenes after the timed region (see bench.py)",
+                    "avg_launch_ms_dual_stream": (round(agg_timed[dom_key][0] / agg_timed[dom_key][1], 4) if dom_key in agg_timed else None),
+                    "launch_timing": "HIP events on the launch stream around every launch of the Python plan walk; single-stream pass of 2 scenes right after the timed region (the timed region replays HIP graphs; see bench.py)",
                     "mfma_issue_ratio": 3, "mfma_hw_tflops": round(3 * ach, 1), "mfma_hw_frac": round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
                     "vs_exact_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
                     # scripts/microbench/mfma_lds.hip: this kernel's tap loop, bare, on random fp16 operands (the nominal peak
@@ -220,7 +229,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
     conv_ms = sum(v[0] for v in agg.values()) / 2.0
-    return dict(seconds=dt, steps=n_steps, voxels=world * n_steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision,
+    return dict(seconds=dt, steps=n_steps, voxels=world * n_steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision, executor=executor,
                 conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / 2.0, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
                 kernel_avg=prof.by_variant(), kernel_avg_timed=kernel_avg_timed)
 
@@ -253,17 +262,16 @@ def bench_shipped_shape(args, device):
         return e0.elapsed_time(e1) / reps, 1e3 * (time.perf_counter() - t0) / reps
 
     res = {"workload": f"{D}^3 x {C} float16 (D,H,W,C) voxel grid -> SegmentationUNet+RegressionUNet forward + combine, 1 scene"}
-    ms, wall = timed(lambda: predict_material_field(seg, cont, load_voxel_grid(grid, device)))
-    res["loader_then_networks"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
-    ms, wall = timed(lambda: predict_material_field_from_voxel_grid(seg, cont, grid))
-    res["fused_first_projector_conv"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
-    seg.use_graph = cont.use_graph = True
     feat32 = load_voxel_grid(grid, device)
-    ms, wall = timed(lambda: predict_material_field(seg, cont, feat32))
-    res["networks_as_hip_graphs_fp32_input_resident"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
-    seg.use_graph = cont.use_graph = False
-    ms, wall = timed(lambda: predict_material_field(seg, cont, feat32))
-    res["networks_eager_fp32_input_resident"] = {"ms_per_scene": ms, "voxels_per_s": D ** 3 / (ms * 1e-3)}
+    legs = {"loader_then_networks": lambda: predict_material_field(seg, cont, load_voxel_grid(grid, device)),
+            "fused_first_projector_conv": lambda: predict_material_field_from_voxel_grid(seg, cont, grid),
+            "networks_only_fp32_input_resident": lambda: predict_material_field(seg, cont, feat32)}
+    for graph in (True, False):          # product default: each network one pixie_unet_forward call replayed as a HIP graph
+        seg.use_graph = cont.use_graph = graph
+        for name, fn in legs.items():
+            ms, wall = timed(fn)
+            res[name + ("" if graph else "_eager")] = {"ms_per_scene": ms, "wall_ms_per_scene": wall, "voxels_per_s": D ** 3 / (ms * 1e-3)}
+    seg.use_graph = cont.use_graph = True
     res["flops_per_scene"] = conv_flops(seg.cfg) + conv_flops(cont.cfg)
     return res
 
@@ -500,7 +508,8 @@ def main():
             "config": {"workload": f"{args.grid}^3x{args.feature_channels} feature grid -> SegmentationUNet+RegressionUNet forward "
                                    f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
                        "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
-                       "weights": "seeded random init of the reference architecture"},
+                       "weights": "seeded random init of the reference architecture",
+                       "executor": u["executor"] + " (one pixie_unet_forward call per network; two networks on two HIP streams)"},
             "unet_tflops": u["flops_scene"] * world * u["steps"] / u["seconds"] / 1e12,
             "unet_conv_ms_per_step": u["conv_ms_per_step"],
             "roofline": u["roofline"],
@@ -526,7 +535,7 @@ def main():
         line["layer_ms_top"] = u["layer_ms"]
         # per kernel NAME, all shapes pooled: comparable with the avg column of profiles/*_kernel_stats.csv (rocprofv3 --stats)
         line["conv_kernel_avg_ms"] = u["kernel_avg"]                           # single-stream pass
-        line["conv_kernel_avg_ms_in_timed_region"] = u["kernel_avg_timed"]    # two streams: launches of the two networks overlap
+        line["conv_kernel_avg_ms_dual_stream"] = u["kernel_avg_timed"]        # two streams: launches of the two networks overlap
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

@@ -191,6 +191,16 @@ typedef struct pixie_conv_desc {
      * up-sampled tensor before concatenating it with an odd-sized skip tensor (diffusion_network.py:925-930), done by not
      * computing the cropped voxels (d_out, d_residual and the output statistics all have the cropped extent). */
     int32_t out_d, out_h, out_w;
+    /* f16x3 path only, optional: the residual block's 1x1x1 skip convolution (MyResBlock.skip_connection,
+     * diffusion_network.py:691,705) folded into this launch:  out = conv(prologue(in)) + bias + skip_conv(skip_in) + skip_bias.
+     * skip_in is the channel concatenation of up to two RAW tensors with the spatial size of the output; d_skip_w16 comes from
+     * pixie_conv_pack_weights_f16x2(w_skip, ., c_out, skip_c0 + skip_c1, 1), d_skip_amax0/1 are the tensors' |x|max slots.
+     * The skip tensor is then never written or read.  Only where pixie_conv_skip_foldable() says so (stride 1, no upsample,
+     * no split-K); d_residual may still be given as well. */
+    const float* d_skip_in0; int32_t skip_c0;
+    const float* d_skip_in1; int32_t skip_c1;
+    const void* d_skip_w16; const float* d_skip_bias;
+    const uint32_t* d_skip_amax0; const uint32_t* d_skip_amax1;
 } pixie_conv_desc;
 
 /* Repack an nn.Conv3d / nn.Conv1d weight (c_out, c_in, k,k,k) into the kernel's
@@ -213,6 +223,9 @@ int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* desc, doub
  * code under its own symbol for the 64 -> 64 full-resolution 3^3 layers), 0 = the exact-fp32 kernel.  For profilers that
  * want to group per-launch timings by kernel name, as rocprofv3 does; no reference counterpart. */
 int pixie_conv_kernel_variant(const pixie_conv_desc* desc, int* slices);
+/* 1 if this descriptor's launch (its shape fields, d_w16 and d_workspace as they will be passed) can take a folded skip
+ * convolution with skip_c0 + skip_c1 input channels; the skip pointers themselves need not be set yet. */
+int pixie_conv_skip_foldable(const pixie_conv_desc* desc);
 
 /* Per-channel sum and sum of squares over the spatial extent: d_sums[2*c] (float64). */
 int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream);

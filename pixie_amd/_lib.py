@@ -50,7 +50,11 @@ class ConvDesc(C.Structure):
                 ("in_bound", C.c_float),
                 ("d_out_stats", C.c_void_p), ("d_out_amax", C.c_void_p),
                 ("d_workspace", C.c_void_p),
-                ("out_d", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32)]
+                ("out_d", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("d_skip_in0", C.c_void_p), ("skip_c0", C.c_int32),
+                ("d_skip_in1", C.c_void_p), ("skip_c1", C.c_int32),
+                ("d_skip_w16", C.c_void_p), ("d_skip_bias", C.c_void_p),
+                ("d_skip_amax0", C.c_void_p), ("d_skip_amax1", C.c_void_p)]
 
 
 class UNetConfigC(C.Structure):
@@ -114,6 +118,7 @@ SIGNATURES = {
     "pixie_attention_forward": (_I, [_VP, _VP, _I, _I, _VP]),
     "pixie_channel_affine": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _VP]),
     "pixie_projector_conv0": (_I, [_VP, _I64, _I, _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _I, _VP]),
+    "pixie_conv_skip_foldable": (_I, [C.POINTER(ConvDesc)]),
     "pixie_unet_create": (_I, [C.POINTER(_VP), C.POINTER(UNetConfigC)]),
     "pixie_unet_destroy": (_I, [_VP]),
     "pixie_unet_param_count": (_I, [_VP]),

@@ -70,6 +70,13 @@ struct Conv16Args {
     float* stats; unsigned* out_amax;   // epilogue statistics (see the epilogue), or null
     float* partial; int chunks_per_slice;   // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps) and writes partial[z]
     int epi_lds;             // the launch reserved enough LDS for the transposing epilogue (4 x 32 x (32 NB + 4) + 256 MB floats)
+    // Folded 1x1x1 skip convolution (MyResBlock.skip_connection, diffusion_network.py:691,705): after the main chunks the
+    // accumulators are rescaled (an exact power of two) and sk_cin more channels of the RAW tensors sk_in0 | sk_in1 are
+    // accumulated through the centre tap only, with their own packed weights, input scale and bias.
+    const float* sk_in0; const float* sk_in1;
+    int sk_c0, sk_cin;
+    const uint4* sk_w16; const float* sk_bias;
+    const unsigned* sk_amax0; const unsigned* sk_amax1;
     int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only,
                              // 4 = phase trace, 32 = one workgroup per CU, bits 8.. = start stagger in us
 };
@@ -322,6 +329,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    float inv2 = 0.0f;   // unscale factor after a folded skip convolution
     if (WS) {
         stage_chunk(0, smem16, tid, NT);     // everybody stages chunk 0
         __syncthreads();
@@ -350,6 +358,87 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
             mfma_chunk(c_base, smem16);
             if (trace && ti < 13) tr[ti++] = wall_clock64();
         }
+        if (A.sk_w16) {
+            // ---- the block's 1x1x1 skip convolution, in the same accumulators (so that out = conv(h) + skip(x) leaves this
+            // launch; the skip tensor is never written or re-read).  acc holds sum (w s_w)(x s_x); the skip products carry
+            // (s_w' s_x') instead, so acc is first multiplied by (s_w' s_x') / (s_w s_x) -- a power of two, exact.
+            float sb = __uint_as_float(*A.sk_amax0);
+            if (A.sk_amax1) sb = fmaxf(sb, __uint_as_float(*A.sk_amax1));
+            const int ex2 = scale_exponent(sb);
+            const float sx2 = pow2i(ex2);
+            const float inv_main = __uint_as_float(A.w16[0].x) * pow2i(-ex);
+            inv2 = __uint_as_float(A.sk_w16[0].x) * pow2i(-ex2);
+            const float ratio = inv_main / inv2;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] *= ratio;
+            const int KG2 = A.sk_cin >> 3;
+            const uint4* w2Hi = A.sk_w16 + kW16HeaderU4 + (size_t)kh * A.coutp + cout0 + l31;
+            const uint4* w2Lo = w2Hi + (size_t)KG2 * A.coutp;          // one tap: the lo plane follows the hi plane
+            const int centre = (KS == 3) ? (A.HY + 1) * A.HX + 1 : 0;   // LDS offset of the tile's own voxels inside the halo'd tile
+            const int tvox = A.TX * A.TY * A.TZ;
+            for (int c2 = 0; c2 < A.sk_cin; c2 += 16) {
+                f16x8 ah[MB], al[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    ah[mb] = __builtin_bit_cast(f16x8, w2Hi[(size_t)(c2 >> 3) * A.coutp + mb * 32]);
+                    al[mb] = __builtin_bit_cast(f16x8, w2Lo[(size_t)(c2 >> 3) * A.coutp + mb * 32]);
+                }
+                __syncthreads();   // previous chunk fully consumed
+                uint4* bHi = smem16;
+                uint4* bLo = smem16 + 2 * A.CS;
+                for (int j = tid; j < tvox; j += NT) {   // raw values, interior voxels only (one tap: no halo)
+                    const int x = j & (A.TX - 1), y = (j >> A.lTX) & (A.TY - 1), z = j >> (A.lTX + A.lTY);
+                    const bool okv = (ox0 + x < A.OW) && (oy0 + y < A.OH) && (oz0 + z < A.OD);
+                    const size_t sidx = okv ? ((size_t)(oz0 + z) * A.IH + (oy0 + y)) * A.IW + ox0 + x : 0;
+                    float val[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int cg = c2 + q;
+                        const float* src = (cg < A.sk_c0) ? (A.sk_in0 + (size_t)cg * ISP) : (A.sk_in1 + (size_t)(cg - A.sk_c0) * ISP);
+                        val[q] = src[sidx];
+                    }
+                    f16x8 vh[2], vl[2];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float sc = okv ? val[q] * sx2 : 0.0f;
+                        const _Float16 hq = (_Float16)sc;
+                        vh[q >> 3][q & 7] = hq;
+                        vl[q >> 3][q & 7] = (_Float16)(sc - (float)hq);
+                    }
+                    const int slot = (z * A.HY + y) * A.HX + x + centre;
+                    bHi[slot] = __builtin_bit_cast(uint4, vh[0]);
+                    bHi[A.CS + slot] = __builtin_bit_cast(uint4, vh[1]);
+                    bLo[slot] = __builtin_bit_cast(uint4, vl[0]);
+                    bLo[A.CS + slot] = __builtin_bit_cast(uint4, vl[1]);
+                }
+                __syncthreads();
+                f16x8 bh[NB], bl[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    bh[nb] = __builtin_bit_cast(f16x8, bHi[voff[nb] + centre]);
+                    bl[nb] = __builtin_bit_cast(f16x8, bLo[voff[nb] + centre]);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+            }
+        }
         if (trace) {
             tr[13] = ti;
             tr[15] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
@@ -361,7 +450,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     // registers: per output channel the sum and sum of squares over this workgroup's voxels (lane -> 32-lane DPP
     // reduction -> 4 waves through LDS) go to stats[tile][c_out_padded][2] with plain stores, and the tile's |x|max
     // to *out_amax; pixie_stats_finalize adds the tiles up in fp64.  That replaces one full read of the tensor.
-    const float inv = __uint_as_float(A.w16[0].x) * pow2i(-ex);
+    const float inv = (!WS && A.sk_w16) ? inv2 : __uint_as_float(A.w16[0].x) * pow2i(-ex);
     if (A.partial) {   // split-K slice: raw partial sums; bias, residual and statistics belong to splitk_reduce_kernel
         float* dst = A.partial + (size_t)blockIdx.z * A.cout * OSP;
 #pragma unroll
@@ -410,7 +499,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
                 const int rowl = (2 * it + kh) * RPI + rsub;
                 const int co = cout0 + mb * 32 + rowl;
                 const float4 a4 = *reinterpret_cast<const float4*>(ldsO + rowl * LDO + colq);
-                const float bv = A.bias ? A.bias[co] : 0.0f;
+                const float bv = (A.bias ? A.bias[co] : 0.0f) + (A.sk_bias ? A.sk_bias[co] : 0.0f);
                 const size_t o = (size_t)co * OSP + ovq;
                 float4 v4;
                 v4.x = a4.x * inv + bv; v4.y = a4.y * inv + bv; v4.z = a4.z * inv + bv; v4.w = a4.w * inv + bv;
@@ -439,7 +528,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
             const int co = cout0 + row;
             float s1 = 0.0f, s2 = 0.0f;
             if (co < A.cout) {
-                const float bv = A.bias ? A.bias[co] : 0.0f;
+                const float bv = (A.bias ? A.bias[co] : 0.0f) + (A.sk_bias ? A.sk_bias[co] : 0.0f);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if (valid[nb]) {
@@ -780,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x3_pipe_kernel(Conv16Args A)
         for (int r = 0; r < 16; ++r) {
             const int co = cout0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (co < A.cout) {
-                const float bv = A.bias ? A.bias[co] : 0.0f;
+                const float bv = (A.bias ? A.bias[co] : 0.0f) + (A.sk_bias ? A.sk_bias[co] : 0.0f);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if (valid[nb]) {
@@ -946,6 +1035,14 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
 
     int MB = 0, NB = 0, slices = 1;
     conv16_tiling(d, a, MB, NB, &slices);
+    if (d->d_skip_w16) {
+        const int scin = d->skip_c0 + d->skip_c1;
+        PX_REQUIRE(pixie_conv_skip_foldable(d), "f16x3 conv: this launch cannot fold a skip convolution (pixie_conv_skip_foldable)");
+        PX_REQUIRE(d->d_skip_in0 && d->d_skip_amax0 && (d->skip_c1 == 0 || (d->d_skip_in1 && d->d_skip_amax1)), "f16x3 conv: folded skip needs its inputs and their amax slots");
+        a.sk_in0 = d->d_skip_in0; a.sk_in1 = d->d_skip_in1; a.sk_c0 = d->skip_c0; a.sk_cin = scin;
+        a.sk_w16 = reinterpret_cast<const uint4*>(d->d_skip_w16); a.sk_bias = d->d_skip_bias;
+        a.sk_amax0 = d->d_skip_amax0; a.sk_amax1 = d->skip_c1 > 0 ? d->d_skip_amax1 : nullptr;
+    }
     if (slices > 1) {
         a.partial = static_cast<float*>(d->d_workspace);
         a.chunks_per_slice = (cin / 16 + slices - 1) / slices;
@@ -978,7 +1075,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     // and enough workgroups that one per CU still fills the chip
     const bool no_pipe = g_conv_no_pipe;
     const size_t lds_pipe = 2 * (lds + 2 * sizeof(uint4));   // two buffers, each with a dummy slot per plane
-    if (!no_pipe && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && lds_pipe <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 512) {
+    if (!no_pipe && !a.sk_w16 && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && lds_pipe <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 512) {
         const bool pro = d->d_pro_a != nullptr, aff = d->d_gamma != nullptr;
         const void* kern = nullptr;
         if (pro && aff && d->act == 1) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, true, 1>);
@@ -998,9 +1095,9 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     }
     // wave-specialised variant: the full 64 x 512 tile of a 3^3 layer, both LDS buffers fit, and at least one
     // workgroup per CU
-    if (g_conv_ws && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
+    if (g_conv_ws && !a.sk_w16 && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
         return launch_f16x3<3, 2, 4, true>(a, 2 * lds, grid, st);
-    if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 &&
+    if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 && !a.sk_w16 &&
         (long)a.OD * a.OH * a.OW >= 128L * 128 * 128) {
         auto kern = conv3d_f16x3_c64_fullres_kernel;
         static bool attr_set = false;
@@ -1065,10 +1162,20 @@ extern "C" int pixie_conv_kernel_variant(const pixie_conv_desc* d, int* slices_o
     int MB = 0, NB = 0, slices = 1;
     conv16_tiling(d, a, MB, NB, &slices);
     if (slices_out) *slices_out = slices;
-    if (d->ksize == 3 && MB == 2 && NB == 4 && d->c0 + d->c1 == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 &&
+    if (d->ksize == 3 && MB == 2 && NB == 4 && d->c0 + d->c1 == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 && !d->d_skip_w16 &&
         (long)a.OD * a.OH * a.OW >= 128L * 128 * 128)
         return 9324;   // conv3d_f16x3_c64_fullres_kernel: the <3,2,4> code under its own symbol
     return d->ksize * 100 + MB * 10 + NB;
+}
+
+extern "C" int pixie_conv_skip_foldable(const pixie_conv_desc* d) {
+    if (!d || !d->d_w16 || d->stride != 1 || d->upsample || (d->ksize != 1 && d->ksize != 3)) return 0;
+    const int scin = d->skip_c0 + d->skip_c1;
+    if (scin <= 0 || scin % 16 != 0 || d->skip_c0 % 8 != 0 || (d->c0 + d->c1) % 16 != 0 || d->c0 % 8 != 0) return 0;
+    Conv16Args a{};
+    int MB = 0, NB = 0, slices = 1;
+    conv16_tiling(d, a, MB, NB, &slices);
+    return slices == 1 ? 1 : 0;
 }
 
 extern "C" int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* d, double* d_sums, void* stream) {

@@ -257,6 +257,7 @@ extern "C" int pixie_conv3d_forward(const pixie_conv_desc* d, void* stream) {
     PX_REQUIRE(!(d->d_gamma && d->upsample), "pixie_conv3d_forward: spatial affine with upsample is not in the reference graph");
 
     if (d->d_w16) return conv3d_f16x3_forward(d, as_stream(stream));
+    PX_REQUIRE(!d->d_skip_w16, "pixie_conv3d_forward: a folded skip convolution needs the f16x3 path (d_w16)");
 
     ConvArgs a{};
     a.in0 = d->d_in0; a.in1 = d->d_in1; a.c0 = d->c0; a.cin = d->c0 + d->c1;

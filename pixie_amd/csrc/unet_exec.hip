@@ -253,7 +253,7 @@ struct pixie_unet {
     uint32_t* d_bound_slots = nullptr;     // 2 words per normalisation layer, device
     std::vector<uint32_t> h_bound_slots;
     std::map<std::tuple<int, int, int>, std::pair<int64_t, int>> sized;   // (d,h,w) -> (workspace bytes, slot count)
-    bool fuse_stats = true, split_k = true;
+    bool fuse_stats = true, split_k = true, fold_skip = true;
 
     const Param& param(const std::string& key) const {
         auto it = index.find(key);
@@ -360,6 +360,22 @@ struct Exec {
         return r;
     }
 
+    bool f16_ok(const std::vector<TP>& parts, int stride) const {    // unet.py: HipOps.f16x3_ok
+        int cin = 0;
+        for (auto& t : parts) cin += t->c;
+        return net->cfg.precision == 0 && (stride == 1 || stride == 2) && cin % 16 == 0 && parts[0]->c % 8 == 0;
+    }
+    bool skip_foldable(const TP& x, int cout, int ksize, const std::vector<TP>& sp) const {   // unet.py: HipOps.skip_foldable
+        pixie_conv_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.c0 = x->c; d.in_d = x->d; d.in_h = x->h; d.in_w = x->w;
+        d.stride = 1; d.ksize = ksize; d.c_out = cout;
+        d.d_w16 = reinterpret_cast<const void*>(0x100);
+        d.d_workspace = net->split_k ? reinterpret_cast<void*>(0x100) : nullptr;
+        d.skip_c0 = sp[0]->c; d.skip_c1 = sp.size() > 1 ? sp[1]->c : 0;
+        return pixie_conv_skip_foldable(&d) != 0;
+    }
+
     // ---- one convolution launch (unet.py: UNetRunner._conv + HipOps.conv) ----
     struct ConvOpt {
         int stride = 1; bool upsample = false;
@@ -367,6 +383,7 @@ struct Exec {
         int act = ACT_NONE; TP residual; float bound = 0.0f;
         int out_d = 0, out_h = 0, out_w = 0;
         float* out_ptr = nullptr;                               // write the result here (caller-owned) instead of into the arena
+        const std::vector<TP>* skip_parts = nullptr; std::string skip_key;   // folded 1x1x1 skip convolution over these raw tensors
     };
     TP conv(const std::vector<TP>& parts, const std::string& wkey, int cout, int ksize, const ConvOpt& o) {
         const TP& x0 = parts[0];
@@ -383,7 +400,7 @@ struct Exec {
         }
         int cin = 0;
         for (auto& t : parts) cin += t->c;
-        const bool f16 = net->cfg.precision == 0 && (o.stride == 1 || o.stride == 2) && cin % 16 == 0 && x0->c % 8 == 0;
+        const bool f16 = f16_ok(parts, o.stride);
         const bool raw = !o.pro && o.affine_store.empty();
         if (f16 && raw) for (auto& t : parts) stats(t);       // the input scale comes from the tensors' device-side |x|max
 
@@ -407,6 +424,15 @@ struct Exec {
             return out;
         }
         desc.d_w16 = w16(wkey);
+        if (o.skip_parts) {
+            const std::vector<TP>& sp = *o.skip_parts;
+            desc.d_skip_in0 = sp[0]->p; desc.skip_c0 = sp[0]->c;
+            desc.d_skip_in1 = sp.size() > 1 ? sp[1]->p : nullptr; desc.skip_c1 = sp.size() > 1 ? sp[1]->c : 0;
+            desc.d_skip_w16 = w16(o.skip_key);
+            desc.d_skip_bias = P(o.skip_key + ".bias");
+            desc.d_skip_amax0 = sp[0]->slot; desc.d_skip_amax1 = sp.size() > 1 ? sp[1]->slot : nullptr;
+            if (dry) desc.d_skip_w16 = reinterpret_cast<const void*>(0x100);
+        }
         if (raw) {
             desc.d_in_amax0 = parts[0]->slot;
             desc.d_in_amax1 = x1 ? parts[1]->slot : nullptr;
@@ -469,8 +495,19 @@ struct Exec {
         stats(h);
         AB pro2 = norm_finalize(h->sums, b.cout, spatial, 0, 1, nullptr, nullptr);
         TP skip = parts[0];
-        if (b.cin != b.cout) skip = conv(parts, p + ".skip_connection", b.cout, 1, ConvOpt{});
-        ConvOpt o2; o2.pro = &pro2; o2.affine_store = p + ".out_layers.0"; o2.act = ACT_LEAKY; o2.residual = skip; o2.bound = norm_bound(p + ".out_layers.0", spatial);
+        ConvOpt o2; o2.pro = &pro2; o2.affine_store = p + ".out_layers.0"; o2.act = ACT_LEAKY; o2.bound = norm_bound(p + ".out_layers.0", spatial);
+        if (b.cin != b.cout) {
+            if (net->fold_skip && f16_ok({h}, 1) && f16_ok(parts, 1) && skip_foldable(h, b.cout, 3, parts)) {
+                // out = conv(h) + skip_connection(x) in ONE launch: the 1x1x1 convolution rides in the accumulators of the second
+                // 3^3 convolution, the skip tensor never exists (conv3d_f16x3.hip, "folded skip")
+                skip.reset();
+                for (auto& t : parts) stats(t);
+                o2.skip_parts = &parts; o2.skip_key = p + ".skip_connection";
+            } else {
+                skip = conv(parts, p + ".skip_connection", b.cout, 1, ConvOpt{});
+            }
+        }
+        o2.residual = skip;
         return conv({h}, p + ".out_layers.3", b.cout, 3, o2);
     }
     TP attn(const Blk& b, const TP& x) {   // AttentionBlock._forward, diffusion_network.py:213-221
@@ -659,6 +696,7 @@ extern "C" int pixie_unet_create(pixie_unet** out, const pixie_unet_config* c) {
         for (size_t i = 0; i < n->params.size(); ++i) n->index[n->params[i].key] = (int)i;
         const char* fs = getenv("PIXIE_FUSE_STATS"); n->fuse_stats = !(fs && fs[0] == '0');
         const char* sk = getenv("PIXIE_CONV_SPLIT_K"); n->split_k = !(sk && sk[0] == '0');
+        const char* fk = getenv("PIXIE_FOLD_SKIP"); n->fold_skip = !(fk && fk[0] == '0');
         *out = n.release();
         return 0;
     });

@@ -90,7 +90,8 @@ class HipOps:
              affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
              residual: Optional[torch.Tensor] = None, w16: Optional[torch.Tensor] = None,
              in_amax: Optional[Sequence[torch.Tensor]] = None, in_bound: float = 0.0,
-             out_amax: Optional[torch.Tensor] = None, out_size: Optional[Tuple[int, int, int]] = None):
+             out_amax: Optional[torch.Tensor] = None, out_size: Optional[Tuple[int, int, int]] = None,
+             skip: Optional[dict] = None):
         """Returns the output tensor; with `out_amax` (f16x3 path) returns (output, channel sums float64 (c_out, 2))
         computed in the conv epilogue, and atomicMax'es |output|max into out_amax."""
         x0 = parts[0]
@@ -127,6 +128,15 @@ class HipOps:
         desc.c_out = cout
         desc.d_residual = residual.data_ptr() if residual is not None else None
         desc.d_out = out.data_ptr()
+        if skip is not None:   # folded 1x1x1 skip convolution: dict(parts, w16, bias, amax)
+            sp = skip["parts"]
+            desc.d_skip_in0 = sp[0].data_ptr(); desc.skip_c0 = sp[0].shape[0]
+            desc.d_skip_in1 = sp[1].data_ptr() if len(sp) > 1 else None
+            desc.skip_c1 = sp[1].shape[0] if len(sp) > 1 else 0
+            desc.d_skip_w16 = skip["w16"].data_ptr()
+            desc.d_skip_bias = skip["bias"].data_ptr() if skip["bias"] is not None else None
+            desc.d_skip_amax0 = skip["amax"][0].data_ptr()
+            desc.d_skip_amax1 = skip["amax"][1].data_ptr() if len(sp) > 1 else None
         sums = None
         if w16 is not None and self.split_k:
             wsb = self.lib.pixie_conv_workspace_bytes(C.byref(desc))
@@ -149,6 +159,19 @@ class HipOps:
         if out_amax is not None:
             return out, sums
         return out
+
+    def skip_foldable(self, x: torch.Tensor, cout: int, ksize: int, skip_parts: Sequence[torch.Tensor]) -> bool:
+        """Would the f16x3 launch of a stride-1 `ksize`^3 convolution x -> cout take a folded 1x1x1 skip convolution over
+        skip_parts (pixie_conv_skip_foldable: channel alignment, and the layer must not be a split-K one)?"""
+        desc = ConvDesc()
+        desc.c0 = x.shape[0]
+        desc.in_d, desc.in_h, desc.in_w = (int(v) for v in x.shape[1:])
+        desc.stride, desc.ksize, desc.c_out = 1, ksize, cout
+        desc.d_w16 = 1                       # "f16x3 weights will be given"
+        desc.d_workspace = 1 if self.split_k else None
+        desc.skip_c0 = skip_parts[0].shape[0]
+        desc.skip_c1 = skip_parts[1].shape[0] if len(skip_parts) > 1 else 0
+        return bool(self.lib.pixie_conv_skip_foldable(C.byref(desc)))
 
     def channel_sums(self, x: torch.Tensor) -> torch.Tensor:
         c = x.shape[0]
@@ -218,6 +241,7 @@ class UNetRunner:
         self._packed16: Dict[str, Tuple[int, int, torch.Tensor]] = {}
         self._bounds: Dict[str, Tuple[int, int, float, float]] = {}
         self.fuse_stats = os.environ.get("PIXIE_FUSE_STATS", "1") != "0"   # channel statistics in the conv epilogue
+        self.fold_skip = os.environ.get("PIXIE_FOLD_SKIP", "1") != "0"     # skip_connection 1x1x1 inside the block's second conv
 
     @property
     def _f16x3(self) -> bool:
@@ -296,7 +320,7 @@ class UNetRunner:
 
     def _conv(self, cache: dict, parts: List[torch.Tensor], wkey: str, cout: int, ksize: int, *, stride: int = 1,
               upsample: bool = False, pro=None, affine_key: Optional[str] = None, act: int = ACT_NONE,
-              residual: Optional[torch.Tensor] = None, bound: float = 0.0, out_size=None) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, bound: float = 0.0, out_size=None, skip=None) -> torch.Tensor:
         """One convolution launch.  `bound` bounds the magnitude of the prologue's output (needed by the f16x3
         kernel to place the tensor in the fp16 range); raw inputs use their device-side |x|max instead."""
         ops = self.ops
@@ -310,6 +334,8 @@ class UNetRunner:
             kw = dict(in_bound=bound)
         if out_size is not None:
             kw["out_size"] = out_size
+        if skip is not None:
+            kw["skip"] = skip
         if self.fuse_stats:
             # the output's channel sums and |x|max come out of the conv epilogue: no separate pass over the tensor
             slot = self._new_slot(cache, parts[0].device)
@@ -331,12 +357,21 @@ class UNetRunner:
         h = self._conv(cache, parts, p + ".in_layers.2", b.cout, 3, pro=pro, affine_key=p + ".in_layers.0", act=ACT_LEAKY,
                        bound=self._norm_bound(p + ".in_layers.0", spatial))
         pro2 = ops.norm_finalize(self._sums(cache, h), spatial, 0)
+        fold = None
         if b.cin != b.cout:
-            skip = self._conv(cache, parts, p + ".skip_connection", b.cout, 1)
+            if (self.fold_skip and self._f16x3 and ops.f16x3_ok([h], 1) and ops.f16x3_ok(parts, 1)
+                    and ops.skip_foldable(h, b.cout, 3, parts)):
+                # out = conv(h) + skip_connection(x) in ONE launch: the 1x1x1 convolution rides in the accumulators of the
+                # second 3^3 convolution, the skip tensor never exists (csrc/conv3d_f16x3.hip, "folded skip")
+                skip = None
+                fold = dict(parts=parts, w16=self._w16(p + ".skip_connection"), bias=self._b(p + ".skip_connection"),
+                            amax=[self._amax(cache, t) for t in parts])
+            else:
+                skip = self._conv(cache, parts, p + ".skip_connection", b.cout, 1)
         else:
             skip = parts[0]
         return self._conv(cache, [h], p + ".out_layers.3", b.cout, 3, pro=pro2, affine_key=p + ".out_layers.0", act=ACT_LEAKY,
-                          residual=skip, bound=self._norm_bound(p + ".out_layers.0", spatial))
+                          residual=skip, bound=self._norm_bound(p + ".out_layers.0", spatial), skip=fold)
 
     def _attn(self, b: Block, x: torch.Tensor, cache: dict) -> torch.Tensor:
         """AttentionBlock._forward, diffusion_network.py:213-221"""
@@ -511,7 +546,9 @@ class _PixieUNet(nn.Module):
         # "python": this file walks the plan and calls one operator at a time (the same launches; needed for `taps`)
         self.executor = os.environ.get("PIXIE_UNET_EXECUTOR", "c")
         self.conv_precision = DEFAULT_PRECISION  # "f16x3" (default) or "f32" (exact-fp32 MFMA everywhere)
-        self.use_graph = os.environ.get("PIXIE_UNET_GRAPH", "0") == "1"   # replay a captured HIP graph per (shape, weights)
+        # replay a captured HIP graph per (shape, precision, parameter versions): the device runs the ~400 launches back to back
+        # (128^3: 49.1 -> 45.5 ms per network) and the host queues ONE launch (16^3: 2.3 -> 0.7 ms).  PIXIE_UNET_GRAPH=0: eager.
+        self.use_graph = os.environ.get("PIXIE_UNET_GRAPH", "1") == "1"
         self._graphs: Dict[tuple, tuple] = {}
 
     @staticmethod
@@ -567,29 +604,30 @@ class _PixieUNet(nn.Module):
             return self._handle.forward(x, proj0)
         return self._runner.forward(x, taps, proj0)
 
-    def _forward_graphed(self, x: torch.Tensor) -> torch.Tensor:
-        """One sample through a captured HIP graph.  A forward pass is ~400 kernel launches driven from Python (ctypes) with
-        ~600 allocations; at 128^3 the device hides that behind 45 ms of kernels, at 32^3 / 64^3 the host is the
-        bottleneck.  The launch sequence of a given (network, input shape, precision, parameter version) never changes, so it
-        is captured once -- after one eager pass that packs the weights and takes the host-side parameter bounds -- and
-        replayed with a single hipGraphLaunch.  Returns a copy of the graph's static output."""
-        key = (tuple(x.shape), self.conv_precision, x.device.index, tuple(p._version for p in self.parameters()))
+    def _forward_graphed(self, x: Optional[torch.Tensor], proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One sample through a captured HIP graph.  A forward pass is ~400 kernel launches; its launch sequence for a given
+        (network, input shape, precision, parameter version) never changes, so it is captured once -- after one eager pass that
+        packs the weights and takes the host-side parameter bounds -- and replayed with a single hipGraphLaunch: the device
+        runs the kernels back to back and the host queues one launch.  Returns a copy of the graph's static output."""
+        src = proj0 if proj0 is not None else x
+        key = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index, tuple(p._version for p in self.parameters()))
+        run = (lambda t: self._forward_one(None, proj0=t)) if proj0 is not None else (lambda t: self._forward_one(t))
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs.clear()                       # a new shape / parameter version invalidates the old capture
-            self._forward_one(x)                       # eager warm-up: weight packing, bounds, function attributes
-            static_in = x.clone()
-            side = torch.cuda.Stream(x.device)
+            run(src)                                   # eager warm-up: weight packing, bounds, function attributes
+            static_in = src.clone()
+            side = torch.cuda.Stream(src.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # capture must not run on the legacy default stream
-                self._forward_one(static_in)
+                run(static_in)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = self._forward_one(static_in)
+                static_out = run(static_in)
             ent = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = ent
-        static_in.copy_(x)
+        static_in.copy_(src)
         graph.replay()
         return static_out.clone()
 
@@ -635,20 +673,24 @@ def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont
     x_seg, x_cont = ops.projector_conv0(g, packed, seg_network.cfg.projector_hidden)
     if dual_stream is None:
         dual_stream = os.environ.get("PIXIE_DUAL_STREAM", "1") == "1"
+
+    def fwd(net, p0):
+        return net._forward_graphed(None, p0) if net.use_graph else net._forward_one(None, proj0=p0)
+
     if dual_stream:   # as in predict_material_field: the two networks on two HIP streams behind the shared first convolution
         cur = torch.cuda.current_stream()
         s1, s2 = _side_streams(dev)
         s1.wait_stream(cur); s2.wait_stream(cur)
         with torch.cuda.stream(s1):
-            seg_logits = seg_network._forward_one(None, proj0=x_seg)[None]
+            seg_logits = fwd(seg_network, x_seg)[None]
         with torch.cuda.stream(s2):
-            cont_pred = cont_network._forward_one(None, proj0=x_cont)[None]
+            cont_pred = fwd(cont_network, x_cont)[None]
         x_seg.record_stream(s1); x_cont.record_stream(s2)
         cur.wait_stream(s1); cur.wait_stream(s2)
         seg_logits.record_stream(cur); cont_pred.record_stream(cur)
     else:
-        seg_logits = seg_network._forward_one(None, proj0=x_seg)[None]
-        cont_pred = cont_network._forward_one(None, proj0=x_cont)[None]
+        seg_logits = fwd(seg_network, x_seg)[None]
+        cont_pred = fwd(cont_network, x_cont)[None]
     combined, seg_pred = ops.combine(seg_logits[0].contiguous(), cont_pred[0].contiguous())
     return combined[None], seg_pred[None], seg_logits, cont_pred
 

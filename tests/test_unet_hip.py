@@ -249,6 +249,70 @@ def test_conv3d_split_k(ops, shape):
     assert rel_l2(a.cpu().numpy(), ref.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [
+    # (c_in of the 3^3 conv, skip parts, c_out, dims, residual too, split_k allowed)
+    (32, (16, 32), 32, (16, 16, 32), False, True),      # 2 chunks: never a split-K layer
+    (64, (64, 64), 64, (64, 64, 64), False, True),      # the decoder shape of the BASELINE network (128 -> 64 blocks), 512 full tiles
+    (64, (64, 64), 64, (9, 10, 11), True, False),       # ragged tiles, residual as well
+    (32, (48,), 40, (8, 12, 20), False, False),         # single skip tensor, c_out padded to 64
+])
+def test_conv3d_folded_skip_convolution(ops, shape):
+    """out = conv3(LN-affine + LeakyReLU (h)) + b + conv1(x) + b_skip in one launch (MyResBlock with a channel change,
+    diffusion_network.py:691,696-705) against fp64 F.conv3d of both convolutions, and against the two-launch route."""
+    cin, skip_c, cout, dims, with_res, allow_split = shape
+    g = torch.Generator().manual_seed(sum(dims) + cin)
+    dev = ops.device
+    h = torch.randn((cin,) + dims, generator=g)
+    xs = [torch.randn((c,) + dims, generator=g) * (3.0 if i else 0.2) for i, c in enumerate(skip_c)]   # different magnitudes: different input scales
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g)
+    ws = torch.randn((cout, sum(skip_c), 1, 1, 1), generator=g) / np.sqrt(sum(skip_c))
+    bs = torch.randn(cout, generator=g)
+    pro = (torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g))
+    affine = (torch.randn(dims, generator=g), torch.randn(dims, generator=g))
+    res = torch.randn((cout,) + dims, generator=g) if with_res else None
+    ref = ref_conv([h], w, b, 1, False, pro, affine, 1, res) + ref_conv(xs, ws, bs)
+    to = lambda t: t.to(dev)
+    dh, dxs = to(h), [to(x) for x in xs]
+    old_split = ops.split_k
+    ops.split_k = allow_split
+    try:
+        assert ops.skip_foldable(dh, cout, 3, dxs)
+        kw = dict(pro=tuple(map(to, pro)), affine=tuple(map(to, affine)), act=1, w16=ops.pack_conv16(to(w)),
+                  in_bound=3.0 * float(_prologue_cpu([h], pro, affine, 1).abs().max()))
+        fold = dict(parts=dxs, w16=ops.pack_conv16(to(ws)), bias=to(bs), amax=_amax_slots(ops, dxs))
+        slot = torch.zeros(1, dtype=torch.int32, device=dev)
+        out, sums = ops.conv([dh], None, to(b), cout, 3, residual=to(res) if with_res else None, skip=fold, out_amax=slot, **kw)
+        out2 = ops.conv([dh], None, to(b), cout, 3, residual=to(res) if with_res else None, skip=fold, **kw)
+        skip_t = ops.conv(dxs, None, to(bs), cout, 1, w16=fold["w16"], in_amax=fold["amax"])
+        if with_res:
+            skip_t = skip_t + to(res)
+        two = ops.conv([dh], None, to(b), cout, 3, residual=skip_t, **kw)
+    finally:
+        ops.split_k = old_split
+    torch.cuda.synchronize()
+    err, err2 = rel_l2(out.cpu().numpy(), ref.numpy()), rel_l2(two.cpu().numpy(), ref.numpy())
+    print(f"folded skip {shape}: rel-L2 {err:.2e} (two launches {err2:.2e})")
+    assert err < 2e-6 and torch.equal(out, out2)
+    if sums is not None:   # the epilogue statistics see the folded result
+        o64 = out.double().reshape(cout, -1)
+        assert torch.allclose(sums[:, 0], o64.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(sums[:, 1], (o64 * o64).sum(1), rtol=1e-5)
+        assert abs(float(slot.view(torch.float32)) - float(out.abs().max())) < 1e-6 * float(out.abs().max())
+
+
+def test_conv3d_skip_fold_is_refused_where_the_layer_splits(ops):
+    """Small-output layers run split-K (partial sums in a workspace): no fold there, and asking for one is an error."""
+    h = torch.randn((128, 8, 8, 8), device=ops.device)
+    xs = [torch.randn((128, 8, 8, 8), device=ops.device), torch.randn((64, 8, 8, 8), device=ops.device)]
+    assert ops.split_k and not ops.skip_foldable(h, 128, 3, xs)
+    w16 = ops.pack_conv16(torch.randn((128, 128, 3, 3, 3), device=ops.device))
+    fold = dict(parts=xs, w16=ops.pack_conv16(torch.randn((128, 192, 1, 1, 1), device=ops.device)), bias=None, amax=_amax_slots(ops, xs))
+    from pixie_amd._lib import PixieHipError
+    with pytest.raises(PixieHipError, match="fold"):
+        ops.conv([h], None, None, 128, 3, w16=w16, in_amax=_amax_slots(ops, [h]), skip=fold)
+    assert not ops.skip_foldable(h[:20], 128, 3, xs)   # channel alignment
+
+
 def test_conv3d_residual_may_alias_output_and_is_deterministic(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn((64, 16, 16, 16), generator=g).to(ops.device)
