@@ -78,7 +78,7 @@ struct Conv16Args {
     const uint4* sk_w16; const float* sk_bias;
     const unsigned* sk_amax0; const unsigned* sk_amax1;
     int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only,
-                             // 4 = phase trace, 32 = one workgroup per CU, bits 8.. = start stagger in us
+                             // 4 = phase trace, 32 = one workgroup per CU, 64 = 18 of 27 taps, 128 = every chunk staged twice, bits 8.. = start stagger in us
 };
 
 __device__ __forceinline__ int fast_div16(int n, int d, unsigned magic) {
@@ -282,8 +282,9 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
             ah[mb] = __builtin_bit_cast(f16x8, wh[mb * 32]);
             al[mb] = __builtin_bit_cast(f16x8, wl[mb * 32]);
         }
+        const int zy_end = (KS == 3 && (A.dbg & 64)) ? 6 : KS * KS;   // timing experiment: 18 of 27 taps (the MFMA count of a 1-D Winograd F(2,3))
 #pragma unroll 1
-        for (int zy = 0; zy < KS * KS; ++zy) {
+        for (int zy = 0; zy < zy_end; ++zy) {
             const int dz = zy / KS, dy = zy - dz * KS;
             const int rowoff = (dz * A.HY + dy) * A.HX;
 #pragma unroll
@@ -353,6 +354,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
         for (int c_base = c_begin; c_base < c_end; c_base += 16) {
             __syncthreads();  // previous chunk fully consumed
             if (!((A.dbg & 2) && c_base > c_begin)) stage_chunk(c_base, smem16, tid, NT);
+            if (A.dbg & 128) { __syncthreads(); stage_chunk(c_base, smem16, tid, NT); }   // timing experiment: staging costs twice
             __syncthreads();
             if (trace && ti < 13) tr[ti++] = wall_clock64();
             mfma_chunk(c_base, smem16);
