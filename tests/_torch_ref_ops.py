@@ -117,8 +117,21 @@ class TorchRefOpsF16x3(TorchRefOps):
         amax_slot.copy_(x.abs().max().reshape(1).float().view(torch.int32))
         return self.channel_sums(x)
 
+    # the HIP launch folds a residual block's 1x1x1 skip convolution where the layer is not a split-K one; the emulation
+    # takes every fold it is offered (same arithmetic: the skip products join the sum before bias / residual / statistics)
+    fold_all = True
+
+    def skip_foldable(self, x, cout, ksize, skip_parts):
+        cin = sum(int(p.shape[0]) for p in skip_parts)
+        return self.fold_all and cin % 16 == 0 and int(skip_parts[0].shape[0]) % 8 == 0
+
     def conv(self, parts, packed_w, bias, cout, ksize, stride=1, upsample=False, pro=None, affine=None, act=0, residual=None,
-             w16=None, in_amax=None, in_bound=0.0, out_amax=None, out_size=None):
+             w16=None, in_amax=None, in_bound=0.0, out_amax=None, out_size=None, skip=None):
+        if skip is not None:   # out = conv(...) + skip_conv(raw skip parts) + skip bias, then the epilogue statistics
+            assert stride == 1 and not upsample and out_size is None and w16 is not None
+            s = self.conv(skip["parts"], None, skip["bias"], cout, 1, w16=skip["w16"], in_amax=skip["amax"])
+            res = s if residual is None else s + residual
+            return self.conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, res, w16, in_amax, in_bound, out_amax)
         if out_size is not None:
             r = self.conv(parts, packed_w, bias, cout, ksize, stride, upsample, pro, affine, act, None, w16, in_amax, in_bound, None)
             y = r[:, :out_size[0], :out_size[1], :out_size[2]].contiguous()
