@@ -8,7 +8,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 ROOT=$(pwd)
 (rocm-smi --showproductname; rocminfo | grep -E "Marketing|gfx|Compute Unit" | head -8) > $OUT/device.txt 2>&1
 python -c "import __graft_entry__ as g; g.build(); print('build ok')" > $OUT/build_check.txt 2>&1
-for mb in mfma_lds valu_rate scatter_variants lds_atomics; do
+for mb in mfma_lds valu_rate valu_rate2 scatter_variants lds_atomics; do
   [ -x scripts/microbench/$mb.exe ] && timeout 120 ./scripts/microbench/$mb.exe > $OUT/${mb}_microbench.txt 2>&1
 done
 run_pmc () {  # name, counters..., -- cmd
