@@ -307,6 +307,11 @@ int64_t pixie_unet_workspace_bytes(pixie_unet* h, int d, int hh, int w);
  * synchronises the stream once to read the normalisation bounds; later calls are launch-only. */
 int pixie_unet_forward(pixie_unet* h, const float* d_feat, const float* d_proj0, int d, int hh, int w, float* d_out,
                        void* d_workspace, int64_t workspace_bytes, void* stream);
+/* Options.  "graph" = 1: pixie_unet_forward records its launch sequence the first time it sees a combination of
+ * (d_feat, d_proj0, d_out, d_workspace) pointers and replays it as ONE hipGraphLaunch on later calls with the same pointers
+ * (a caller that keeps its buffers; up to 4 combinations are kept; pixie_unet_set_param invalidates them).  Needs a
+ * non-default stream.  Same kernels, same arguments: bit-identical output. */
+int pixie_unet_set_option(pixie_unet* h, const char* key, int value);
 
 /* ======================================================================================
  * (C) Field -> particle transfer between the two halves: replaces the PLY round trip

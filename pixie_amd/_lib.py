@@ -125,6 +125,7 @@ SIGNATURES = {
     "pixie_unet_param_info": (_I, [_VP, _I, C.POINTER(_S), C.POINTER(_I64), C.POINTER(C.c_int32), C.POINTER(_I64)]),
     "pixie_unet_set_param": (_I, [_VP, _S, _VP, _I64]),
     "pixie_unet_workspace_bytes": (_I64, [_VP, _I, _I, _I]),
+    "pixie_unet_set_option": (_I, [_VP, _S, _I]),
     "pixie_unet_forward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _I64, _VP]),
     "pixie_combine_class_ids": (_I, [_VP, _I, _VP, _I64, _VP, _VP]),
     "pixie_combine_predictions": (_I, [_VP, _I, _VP, _I64, _VP, _VP, _VP]),

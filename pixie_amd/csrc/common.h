@@ -25,6 +25,10 @@ int set_error(const char* fmt, ...);
     } while (0)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KB for `kern` on the CURRENT device, once per (kernel, device), thread-safe
+// (a process may drive several GPUs; a function-local `static bool` would cover only the first).  Defined in common.hip.
+hipError_t allow_max_dynamic_lds(const void* kern);
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace pixie

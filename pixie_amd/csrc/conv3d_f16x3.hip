@@ -938,11 +938,7 @@ static int pow2_le16(int v, int cap) { int p = 1; while (p * 2 <= v && p * 2 <= 
 template <int KS, int MB, int NB, bool WS = false>
 static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStream_t st) {
     auto kern = conv3d_f16x3_kernel<KS, MB, NB, WS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
     hipLaunchKernelGGL(kern, grid, dim3(WS ? 512 : 256), lds_bytes, st, a);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1085,11 +1081,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
         else if (pro && !aff && d->act == 2) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, false, 2>);
         else if (pro && !aff && d->act == 0) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, false, 0>);
         if (kern) {
-            static std::map<const void*, bool> attr_set;
-            if (!attr_set[kern]) {
-                PX_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set[kern] = true;
-            }
+            PX_CHECK_HIP(allow_max_dynamic_lds(kern));
             void* args[] = {const_cast<Conv16Args*>(&a)};
             PX_CHECK_HIP(hipLaunchKernel(kern, grid, dim3(256), args, lds_pipe, st));
             return 0;
@@ -1102,11 +1094,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 && !a.sk_w16 &&
         (long)a.OD * a.OH * a.OW >= 128L * 128 * 128) {
         auto kern = conv3d_f16x3_c64_fullres_kernel;
-        static bool attr_set = false;
-        if (!attr_set) {
-            PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
         PX_CHECK_HIP(hipGetLastError());
         return 0;

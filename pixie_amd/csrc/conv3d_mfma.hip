@@ -218,11 +218,7 @@ static int pow2_le(int v, int cap) { int p = 1; while (p * 2 <= v && p * 2 <= ca
 template <int KS, int MB, int NB, int CK>
 static int launch_variant(const ConvArgs& a, size_t lds_bytes, dim3 grid, hipStream_t st) {
     auto kern = conv3d_mfma_kernel<KS, MB, NB, CK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
     PX_CHECK_HIP(hipGetLastError());
     return 0;

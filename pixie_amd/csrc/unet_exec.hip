@@ -254,6 +254,17 @@ struct pixie_unet {
     std::vector<uint32_t> h_bound_slots;
     std::map<std::tuple<int, int, int>, std::pair<int64_t, int>> sized;   // (d,h,w) -> (workspace bytes, slot count)
     bool fuse_stats = true, split_k = true, fold_skip = true;
+    // pixie_unet_set_option("graph", 1): forward() replays a captured HIP graph when called again with the same pointers
+    struct Replay { const float* feat; const float* proj0; float* out; void* ws; int d; uint64_t epoch; hipGraph_t graph; hipGraphExec_t exec; };
+    bool use_graph = false;
+    uint64_t epoch = 0;                     // bumped by every set_param: captured kernel arguments (bounds, weights) are stale after it
+    std::vector<Replay> replays;            // most recently used last; at most kMaxReplays
+    static constexpr size_t kMaxReplays = 4;
+    void drop_replay(size_t i) {
+        (void)hipGraphExecDestroy(replays[i].exec);
+        (void)hipGraphDestroy(replays[i].graph);
+        replays.erase(replays.begin() + (long)i);
+    }
 
     const Param& param(const std::string& key) const {
         auto it = index.find(key);
@@ -398,8 +409,6 @@ struct Exec {
             od = std::min(od, o.out_d); oh = std::min(oh, o.out_h); ow = std::min(ow, o.out_w);
             desc.out_d = od; desc.out_h = oh; desc.out_w = ow;
         }
-        int cin = 0;
-        for (auto& t : parts) cin += t->c;
         const bool f16 = f16_ok(parts, o.stride);
         const bool raw = !o.pro && o.affine_store.empty();
         if (f16 && raw) for (auto& t : parts) stats(t);       // the input scale comes from the tensors' device-side |x|max
@@ -707,6 +716,7 @@ extern "C" int pixie_unet_destroy(pixie_unet* h) {
     for (auto& kv : h->packed16) if (kv.second.d) (void)hipFree(kv.second.d);
     for (auto& kv : h->packed32) if (kv.second.d) (void)hipFree(kv.second.d);
     if (h->d_bound_slots) (void)hipFree(h->d_bound_slots);
+    while (!h->replays.empty()) h->drop_replay(0);
     delete h;
     return 0;
 }
@@ -731,6 +741,7 @@ extern "C" int pixie_unet_set_param(pixie_unet* h, const char* key, const float*
     PX_REQUIRE(numel == p.numel, "pixie_unet_set_param: '%s' has %lld elements, got %lld", key, (long long)p.numel, (long long)numel);
     p.d = d_values;
     ++p.version;
+    ++h->epoch;
     return 0;
 }
 
@@ -752,15 +763,53 @@ extern "C" int pixie_unet_forward(pixie_unet* h, const float* d_feat, const floa
         const auto sized = size_pass(h, d, hh, w);
         if (workspace_bytes < sized.first)
             fail("pixie_unet_forward: workspace of %lld bytes, this grid needs %lld (pixie_unet_workspace_bytes)", (long long)workspace_bytes, (long long)sized.first);
+        auto launch_all = [&] {
+            Exec ex;
+            ex.net = h; ex.dry = false; ex.stream = stream;
+            const int64_t slot_bytes = slot_region_bytes(sized.second);
+            ex.slots = static_cast<uint32_t*>(d_workspace);
+            ex.slot_cap = sized.second;
+            if (hipMemsetAsync(d_workspace, 0, (size_t)slot_bytes, as_stream(stream)) != hipSuccess) fail("pixie_unet_forward: hipMemsetAsync failed");
+            ex.arena.reset(static_cast<char*>(d_workspace) + slot_bytes, workspace_bytes - slot_bytes);
+            TP out = ex.forward(d_feat, d_proj0, d, hh, w, d_out);
+        };
+        if (h->use_graph) {
+            for (size_t i = 0; i < h->replays.size(); ++i) {
+                const pixie_unet::Replay& r = h->replays[i];
+                if (r.feat != d_feat || r.proj0 != d_proj0 || r.out != d_out || r.ws != d_workspace || r.d != d) continue;
+                if (r.epoch != h->epoch) { h->drop_replay(i); break; }   // parameters changed since the capture
+                if (hipGraphLaunch(r.exec, as_stream(stream)) != hipSuccess) fail("pixie_unet_forward: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+                if (i + 1 != h->replays.size()) std::rotate(h->replays.begin() + (long)i, h->replays.begin() + (long)i + 1, h->replays.end());
+                return 0;
+            }
+        }
         refresh_bounds(h, stream);
-        Exec ex;
-        ex.net = h; ex.dry = false; ex.stream = stream;
-        const int64_t slot_bytes = slot_region_bytes(sized.second);
-        ex.slots = static_cast<uint32_t*>(d_workspace);
-        ex.slot_cap = sized.second;
-        if (hipMemsetAsync(d_workspace, 0, (size_t)slot_bytes, as_stream(stream)) != hipSuccess) fail("pixie_unet_forward: hipMemsetAsync failed");
-        ex.arena.reset(static_cast<char*>(d_workspace) + slot_bytes, workspace_bytes - slot_bytes);
-        TP out = ex.forward(d_feat, d_proj0, d, hh, w, d_out);
+        launch_all();               // eager: packs what needs packing, and IS this call's result
+        if (h->use_graph) {
+            // the same launch sequence once more, recorded instead of executed, for the next call with these pointers
+            hipStream_t st = as_stream(stream);
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess)
+                fail("pixie_unet_forward: cannot capture on this stream (graph replay needs a non-default stream): %s", hipGetErrorString(hipGetLastError()));
+            hipGraph_t graph = nullptr;
+            try { launch_all(); }
+            catch (...) { (void)hipStreamEndCapture(st, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+            if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) fail("pixie_unet_forward: hipStreamEndCapture failed: %s", hipGetErrorString(hipGetLastError()));
+            hipGraphExec_t exec = nullptr;
+            if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); fail("pixie_unet_forward: hipGraphInstantiate failed"); }
+            if (h->replays.size() >= pixie_unet::kMaxReplays) h->drop_replay(0);
+            h->replays.push_back(pixie_unet::Replay{d_feat, d_proj0, d_out, d_workspace, d, h->epoch, graph, exec});
+        }
         return 0;
     });
+}
+
+extern "C" int pixie_unet_set_option(pixie_unet* h, const char* key, int value) {
+    PX_REQUIRE(h && key, "pixie_unet_set_option: null argument");
+    const std::string k(key);
+    if (k == "graph") {
+        h->use_graph = value != 0;
+        if (!h->use_graph) while (!h->replays.empty()) h->drop_replay(0);
+        return 0;
+    }
+    return set_error("pixie_unet_set_option: unknown key '%s' (known: graph)", key);
 }

@@ -301,13 +301,7 @@ static int launch_attention(const float* qkv, float* out, int T, hipStream_t st)
     auto kern = attention_kernel<C>;
     // the attribute belongs to the (function, device) pair and a process may drive several devices: once per device
     // (not per launch: the call is not a stream operation and must stay out of HIP-graph captures)
-    static unsigned long long attr_set_mask = 0ull;
-    int dev = 0;
-    PX_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_set_mask >> dev) & 1ull)) {
-        PX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (dev < 64) attr_set_mask |= 1ull << dev;
-    }
+    PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
     hipLaunchKernelGGL(kern, dim3((T + ATT_BQ - 1) / ATT_BQ), dim3(ATT_WAVES * 64), lds, st, qkv, out, T);
     PX_CHECK_HIP(hipGetLastError());
     return 0;

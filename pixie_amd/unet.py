@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import warnings
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -615,16 +616,23 @@ class _PixieUNet(nn.Module):
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs.clear()                       # a new shape / parameter version invalidates the old capture
-            run(src)                                   # eager warm-up: weight packing, bounds, function attributes
-            static_in = src.clone()
-            side = torch.cuda.Stream(src.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):              # capture must not run on the legacy default stream
-                run(static_in)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = run(static_in)
+            out = run(src)                             # eager warm-up: weight packing, bounds, function attributes
+            try:
+                static_in = src.clone()
+                side = torch.cuda.Stream(src.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):          # capture must not run on the legacy default stream
+                    run(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: calls other threads make meanwhile (e.g. the RCCL watchdog of a multi-GPU job) do not void the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    static_out = run(static_in)
+            except RuntimeError as exc:                # same kernels either way: fall back to launching them one by one, loudly
+                warnings.warn(f"pixie_amd: HIP-graph capture of the U-Net forward failed ({exc}); continuing with eager launches",
+                              RuntimeWarning)
+                self.use_graph = False
+                return out
             ent = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = ent
         static_in.copy_(src)

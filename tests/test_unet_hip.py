@@ -500,6 +500,54 @@ def test_unet_handle_follows_parameter_updates_and_rejects_bad_calls(hip_device)
     assert torch.equal(h.forward(feat[0]), y1[0])
 
 
+def test_unet_handle_replays_its_own_hip_graph(hip_device):
+    """pixie_unet_set_option("graph", 1): a caller that keeps its buffers gets ONE hipGraphLaunch per forward from the second
+    call on (no torch involved in the capture); new input values in the same buffer, and a parameter update, are followed."""
+    from pixie_amd import _lib
+    from pixie_amd.unet import SegmentationUNet, UNetHandle
+    kw, wseed, iseed = CASES["full16"]
+    model = SegmentationUNet(kw["feature_channels"], kw["cond_dim"], kw["model_channels"], kw["num_res_blocks"], kw["channel_mult"],
+                             kw["attention_resolutions"], kw["grid_size"], 8)
+    model.load_numpy_state(synthetic_state_dict(model.cfg, wseed))
+    model = model.to(hip_device).eval()
+    model.use_graph = False
+    D = kw["grid_size"]
+    feats = [torch.from_numpy(feature_grid(D, kw["feature_channels"], seed=iseed + i)).to(hip_device)[0].contiguous() for i in range(3)]
+    eager = [model(f[None])[0] for f in feats]
+    h = UNetHandle(model.cfg, "f16x3", hip_device)
+    h.load({k: v for k, v in model.named_parameters()})
+    lib = _lib.load()
+    assert lib.pixie_unet_set_option(h._h, b"graph", 1) == 0
+    assert lib.pixie_unet_set_option(h._h, b"no_such_option", 1) != 0
+    nbytes = h.workspace_bytes(D, D, D)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=hip_device)
+    x = torch.empty_like(feats[0])
+    out = torch.empty((8, D, D, D), device=hip_device)
+    side = torch.cuda.Stream(hip_device)
+    side.wait_stream(torch.cuda.current_stream())
+
+    def call():
+        with torch.cuda.stream(side):
+            _lib.check(lib.pixie_unet_forward(h._h, x.data_ptr(), None, D, D, D, out.data_ptr(), ws.data_ptr(), nbytes, _lib.current_stream_ptr()),
+                       "pixie_unet_forward")
+        side.synchronize()
+
+    for i in (0, 1, 2, 1):           # call 0: eager + capture; later calls: replay on new values in the same buffers
+        x.copy_(feats[i]); torch.cuda.synchronize()
+        call()
+        assert torch.equal(out, eager[i]), f"graph replay differs from the eager pass (call with input {i})"
+    with torch.no_grad():
+        model.unet.out._modules["0"].weight.mul_(3.0)
+    want = model(feats[0][None])[0]
+    h.load({k: v for k, v in model.named_parameters()})      # set_param: the recorded graph is stale and must not be replayed
+    x.copy_(feats[0]); torch.cuda.synchronize()
+    call(); assert torch.equal(out, want)
+    call(); assert torch.equal(out, want)
+    # the legacy default stream cannot be captured: a clear error, not a crash
+    rc = lib.pixie_unet_forward(h._h, x.data_ptr(), None, D, D, D, out.data_ptr(), ws.data_ptr() + 256, nbytes - 256, None)
+    assert rc != 0 and (b"capture" in lib.pixie_last_error() or b"workspace" in lib.pixie_last_error())
+
+
 def test_predict_material_field_and_batch(hip_device):
     from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
     kw = dict(feature_channels=64, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4),
