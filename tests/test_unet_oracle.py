@@ -71,6 +71,26 @@ def test_plan_structure_matches_survey_appendix():
     assert abs(conv_flops(cfg) / 13527.7e9 - 1) < 5e-3
 
 
+def test_oracle_structure_is_its_own_and_agrees_with_the_product():
+    """oracle/unet_oracle.py restates MyUNetModel.__init__ itself (it imports nothing from pixie_amd/), and that restatement, the
+    product's Python plan and -- through tests/test_unet_handle.py -- the C handle's table name the same parameters in the
+    same order, for every architecture variant the goldens cover plus the BASELINE ones."""
+    import ast
+    src = open(unet_oracle.__file__).read()
+    imported = [n.module or "" for n in ast.walk(ast.parse(src)) if isinstance(n, ast.ImportFrom)] + \
+               [a.name for n in ast.walk(ast.parse(src)) if isinstance(n, ast.Import) for a in n.names]
+    assert not any(m.startswith("pixie_amd") for m in imported), imported
+    variants = [UNetConfig(out_channels=oc, **kw) for kw, _, _ in CASES.values() for _, oc, _ in HEADS]
+    variants += [UNetConfig(grid_size=128, out_channels=8), UNetConfig(768, 32, 64, 3, (1, 1, 2, 4), (8,), 64, 3),
+                 UNetConfig(128, 32, 64, 3, (1, 1, 2, 4), (), 256, 8), UNetConfig(16, 16, 16, 1, (1, 2), (1, 2), 9, 3)]
+    for cfg in variants:
+        assert unet_oracle.state_dict_keys(cfg) == list(param_shapes(cfg).keys()), cfg
+        plan = build_plan(cfg)
+        ins, mid, outs = unet_oracle.structure(cfg)
+        flat = lambda seqs: [(b.kind, b.prefix, b.cin, b.cout) for seq in seqs for b in seq]
+        assert flat(ins) == flat(plan.input_blocks) and flat([mid]) == flat([plan.middle]) and flat(outs) == flat(plan.output_blocks)
+
+
 @pytest.mark.parametrize("name", ["full16", "noproj_attn8", "lightproj8"])
 def test_runner_wiring_against_oracle(name):
     """pixie_amd.unet.UNetRunner with torch stand-ins for the five HIP operators reproduces the oracle:
