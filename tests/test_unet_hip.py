@@ -143,6 +143,41 @@ def test_conv3d_f16x3_dynamic_range(ops):
     assert per < 1e-5, per
 
 
+@pytest.mark.parametrize("outlier", [1.0, 100.0, 1.0e4])
+def test_conv3d_f16x3_layernorm_prologue_with_outlier_gamma(ops, outlier):
+    """A LayerNorm-prologue convolution whose spatial affine weight has ONE voxel `outlier` times larger than the rest, scaled the
+    way the executors scale it: in_bound = sqrt(N) max|gamma| + max|beta| (a standardised sample of N values cannot exceed
+    sqrt(N - 1)).  The bound is loose by construction -- sqrt(N) wastes log2(sqrt(N)/typical max) bits of the fp16 exponent, the
+    outlier the rest -- and the split degrades gracefully: the lo halves of ordinary voxels slide into fp16 subnormals (quantum
+    2^-24 of the scaled range).  Measured: 2.0e-7 on the ordinary voxels up to a 100x outlier, 9.6e-7 at 10^4 (where the
+    outlier voxel really spans 2^13 of dynamic range) -- two orders below the 1e-4 end-to-end bar."""
+    g = torch.Generator().manual_seed(17)
+    dims = (16, 16, 32)
+    n = dims[0] * dims[1] * dims[2]
+    x = torch.randn((64,) + dims, generator=g) * 3.0 + 1.0
+    w = torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)
+    b = torch.randn(64, generator=g)
+    mean = x.reshape(64, -1).mean(1); var = x.reshape(64, -1).var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    pro = (rstd, -mean * rstd)
+    gamma = 1.0 + 0.1 * torch.randn(dims, generator=g)
+    beta = 0.1 * torch.randn(dims, generator=g)
+    gamma[3, 4, 5] *= outlier
+    ref = ref_conv([x], w, b, 1, False, pro, (gamma, beta), 1, None)
+    to = lambda t: t.to(ops.device)
+    bound = float(np.sqrt(n) * gamma.abs().max() + beta.abs().max())
+    out = ops.conv([to(x)], None, to(b), 64, 3, pro=tuple(map(to, pro)), affine=(to(gamma), to(beta)), act=1, w16=ops.pack_conv16(to(w)),
+                   in_bound=bound)
+    assert torch.isfinite(out).all()
+    err = rel_l2(out.cpu().numpy(), ref.numpy())
+    # away from the outlier's 3^3 neighbourhood (whose outputs are dominated by the one huge input) the ordinary voxels must stay accurate
+    mask = torch.ones(dims, dtype=torch.bool); mask[1:6, 2:7, 3:8] = False
+    o, r = out.cpu().double()[:, mask], ref[:, mask]
+    err_rest = float((o - r).norm() / r.norm())
+    print(f"LayerNorm prologue, gamma outlier x{outlier:g}: rel-L2 {err:.2e} overall, {err_rest:.2e} away from the outlier (in_bound {bound:.3g})")
+    assert err < 2e-6 and err_rest < (1e-6 if outlier <= 100.0 else 5e-6), (err, err_rest)
+
+
 @pytest.mark.parametrize("variant", ["ln_leaky", "raw", "gn_silu", "gn_none", "concat_ln"])
 def test_conv3d_kernel_variants_are_bit_identical(ops, variant):
     """The three f16x3 kernels for the dominant 3^3 layers -- plain (2 workgroups per CU; the default), experimental
