@@ -169,6 +169,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
             pd.all_gather_fields(cont_pred, seg_pred)
         return combined
 
+    step()   # set-up, not a warm-up step: packs the weights, takes the normalisation bounds and records the HIP graphs
     for _ in range(n_warm):
         step()
     executor = f"{seg.executor}{'+hip_graph' if seg.use_graph else ''}"
