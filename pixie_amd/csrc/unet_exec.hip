@@ -31,6 +31,10 @@
 #include "common.h"
 
 namespace pixie {
+// internal entry points of unet_ops.hip (the launches of pixie_channel_stats / pixie_norm_finalize without their set-up work)
+int channel_stats_prezeroed(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, hipStream_t st);
+int norm_finalize_cat(const double* d_sums0, int c0, const double* d_sums1, int c1, int64_t spatial, int mode, int groups, double eps,
+                      const float* d_weight, const float* d_bias, float* d_a, float* d_b, hipStream_t st);
 namespace {
 
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SILU = 2 };
@@ -227,7 +231,8 @@ struct Tens {
     float* p = nullptr;
     int64_t off = -1;             // arena offset, -1: caller-owned
     int c = 0, d = 0, h = 0, w = 0;
-    int64_t sums_off = -1;        // double[2c] channel sums of this tensor, once somebody needed them
+    int64_t sums_off = -1;        // arena range of `sums` when a conv epilogue produced them (-1: pre-zeroed region, or none yet)
+    bool has_sums = false;        // double[2c] channel sums of this tensor exist (somebody needed them)
     double* sums = nullptr;
     uint32_t* slot = nullptr;     // |x|max as float bits
     int64_t spatial() const { return (int64_t)d * h * w; }
@@ -236,6 +241,7 @@ struct Tens {
 using TP = std::shared_ptr<Tens>;
 
 struct Packed { void* d = nullptr; uint64_t version = ~0ull; };
+struct Sized { int64_t bytes; int slots; int64_t zsum_doubles; };   // workspace bytes, |x|max words, pre-zeroed statistics doubles
 struct Bound { float wmax = 0, bmax = 0; uint64_t wver = ~0ull, bver = ~0ull; };
 
 }  // namespace
@@ -252,7 +258,7 @@ struct pixie_unet {
     std::unordered_map<std::string, Bound> bounds;
     uint32_t* d_bound_slots = nullptr;     // 2 words per normalisation layer, device
     std::vector<uint32_t> h_bound_slots;
-    std::map<std::tuple<int, int, int>, std::pair<int64_t, int>> sized;   // (d,h,w) -> (workspace bytes, slot count)
+    std::map<std::tuple<int, int, int, bool>, Sized> sized;   // (d, h, w, starts behind projector.net[0]) -> what one pass needs
     bool fuse_stats = true, split_k = true, fold_skip = true;
     // pixie_unet_set_option("graph", 1): forward() replays a captured HIP graph when called again with the same pointers
     struct Replay { const float* feat; const float* proj0; float* out; void* ws; int d; uint64_t epoch; hipGraph_t graph; hipGraphExec_t exec; };
@@ -281,8 +287,11 @@ struct Exec {
     Arena arena;
     bool dry = false;
     void* stream = nullptr;
-    uint32_t* slots = nullptr;    // zeroed words at the head of the workspace
+    // head of the workspace, zeroed by ONE memset per pass: |x|max words, then the double[2c] targets of the statistics passes
+    uint32_t* slots = nullptr;
     int slot_next = 0, slot_cap = 0;
+    double* zsums = nullptr;
+    int64_t zsum_next = 0, zsum_cap = 0;
 
     TP make(int c, int d, int h, int w) {
         auto t = std::make_shared<Tens>();
@@ -354,11 +363,13 @@ struct Exec {
 
     // ---- statistics ----
     void stats(const TP& t) {                  // channel sums + |x|max by a pass over the tensor (only where no conv epilogue produced them)
-        if (t->sums_off >= 0) return;
-        t->sums_off = arena.alloc((int64_t)t->c * 2 * sizeof(double));
-        t->sums = arena.ptr<double>(t->sums_off);
+        if (t->has_sums) return;
+        t->has_sums = true;
+        if (!dry && zsum_next + 2 * t->c > zsum_cap) fail("pixie_unet_forward: out of statistics space (internal sizing error)");
+        t->sums = dry ? nullptr : zsums + zsum_next;      // the kernel adds into zeroed memory (fp64 atomics)
+        zsum_next += 2 * t->c;
         t->slot = new_slot();
-        if (!dry) ok(pixie_channel_stats(t->p, t->c, t->spatial(), t->sums, t->slot, stream), "pixie_channel_stats");
+        if (!dry) ok(channel_stats_prezeroed(t->p, t->c, t->spatial(), t->sums, t->slot, as_stream(stream)), "pixie_channel_stats");
     }
     struct AB { std::shared_ptr<Scratch> mem; float* a; float* b; };
     AB norm_finalize(const double* sums, int c, int64_t spatial, int mode, int groups, const float* w, const float* b) {
@@ -472,33 +483,30 @@ struct Exec {
         if (have_stats) {
             out->sums_off = arena.alloc((int64_t)cout * 2 * sizeof(double));
             out->sums = arena.ptr<double>(out->sums_off);
+            out->has_sums = true;
             if (!dry) ok(pixie_stats_finalize(desc.d_out_stats, &desc, out->sums, stream), "pixie_stats_finalize");
         }
         return out;
     }
 
     // ---- blocks ----
-    const double* sums_of(const std::vector<TP>& parts, std::unique_ptr<Scratch>& joined) {
+    AB norm_finalize_parts(const std::vector<TP>& parts, int64_t spatial) {   // LayerNorm statistics of th.cat(parts): read where they lie
         for (auto& t : parts) stats(t);
-        if (parts.size() == 1) return parts[0]->sums;
-        int c = 0;
-        for (auto& t : parts) c += t->c;
-        joined.reset(new Scratch(this, (int64_t)c * 2 * sizeof(double)));   // th.cat of the statistics, not of the tensors
-        double* dst = joined->as<double>();
-        int at = 0;
-        for (auto& t : parts) {
-            if (!dry && hipMemcpyAsync(dst + 2 * at, t->sums, (size_t)t->c * 2 * sizeof(double), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
-                fail("pixie_unet_forward: hipMemcpyAsync failed");
-            at += t->c;
-        }
-        return dst;
+        if (parts.size() == 1) return norm_finalize(parts[0]->sums, parts[0]->c, spatial, 0, 1, nullptr, nullptr);
+        const int c0 = parts[0]->c, c1 = parts[1]->c, c = c0 + c1;
+        AB r;
+        const int cpad = (c + 63) / 64 * 64;
+        r.mem = std::make_shared<Scratch>(this, (int64_t)(cpad + c) * sizeof(float));
+        r.a = r.mem->as<float>();
+        r.b = r.a + cpad;
+        if (!dry) ok(norm_finalize_cat(parts[0]->sums, c0, parts[1]->sums, c1, spatial, 0, 1, 1e-5, nullptr, nullptr, r.a, r.b, as_stream(stream)),
+                     "pixie_norm_finalize");
+        return r;
     }
     TP res(const Blk& b, const std::vector<TP>& parts) {   // MyResBlock.forward, diffusion_network.py:696-705
         const std::string& p = b.prefix;
         const int64_t spatial = parts[0]->spatial();
-        std::unique_ptr<Scratch> joined;
-        const double* s = sums_of(parts, joined);
-        AB pro = norm_finalize(s, b.cin, spatial, 0, 1, nullptr, nullptr);
+        AB pro = norm_finalize_parts(parts, spatial);
         ConvOpt o1; o1.pro = &pro; o1.affine_store = p + ".in_layers.0"; o1.act = ACT_LEAKY; o1.bound = norm_bound(p + ".in_layers.0", spatial);
         TP h = conv(parts, p + ".in_layers.2", b.cout, 3, o1);
         stats(h);
@@ -662,18 +670,20 @@ void refresh_bounds(pixie_unet* net, void* stream) {
 
 constexpr int64_t kSlotAlign = 256;
 int64_t slot_region_bytes(int n_slots) { return ((int64_t)n_slots * 4 + kSlotAlign - 1) / kSlotAlign * kSlotAlign; }
+int64_t zsum_region_bytes(int64_t n_doubles) { return (n_doubles * 8 + kSlotAlign - 1) / kSlotAlign * kSlotAlign; }
 
-std::pair<int64_t, int> size_pass(pixie_unet* net, int D, int H, int W) {
-    auto key = std::make_tuple(D, H, W);
+Sized size_pass(pixie_unet* net, int D, int H, int W, bool from_proj0) {
+    auto key = std::make_tuple(D, H, W, from_proj0);
     auto it = net->sized.find(key);
     if (it != net->sized.end()) return it->second;
     Exec ex;
     ex.net = net; ex.dry = true; ex.stream = nullptr;
     ex.arena.reset(reinterpret_cast<char*>(0x10000000), (int64_t)1 << 50);   // addresses of the dry run are never dereferenced
     {
-        TP out = ex.forward(reinterpret_cast<const float*>(0x100), nullptr, D, H, W, reinterpret_cast<float*>(0x100));
+        const float* fake = reinterpret_cast<const float*>(0x100);
+        TP out = ex.forward(from_proj0 ? nullptr : fake, from_proj0 ? fake : nullptr, D, H, W, reinterpret_cast<float*>(0x100));
     }
-    auto r = std::make_pair(ex.arena.peak + slot_region_bytes(ex.slot_next), ex.slot_next);
+    Sized r{ex.arena.peak + slot_region_bytes(ex.slot_next) + zsum_region_bytes(ex.zsum_next), ex.slot_next, ex.zsum_next};
     net->sized[key] = r;
     return r;
 }
@@ -748,7 +758,11 @@ extern "C" int pixie_unet_set_param(pixie_unet* h, const char* key, const float*
 extern "C" int64_t pixie_unet_workspace_bytes(pixie_unet* h, int d, int hh, int w) {
     if (!h || d <= 0 || hh <= 0 || w <= 0) { set_error("pixie_unet_workspace_bytes: bad argument"); return -1; }
     int64_t bytes = -1;
-    const int rc = guarded([&] { bytes = size_pass(h, d, hh, w).first; return 0; });
+    const int rc = guarded([&] {   // enough for either entry: from the feature grid, or behind an externally computed projector.net[0]
+        bytes = size_pass(h, d, hh, w, false).bytes;
+        if (h->cfg.projector_hidden() > 0) bytes = std::max(bytes, size_pass(h, d, hh, w, true).bytes);
+        return 0;
+    });
     return rc == 0 ? bytes : -1;
 }
 
@@ -760,17 +774,19 @@ extern "C" int pixie_unet_forward(pixie_unet* h, const float* d_feat, const floa
     PX_REQUIRE(!d_proj0 || h->cfg.projector_hidden() > 0, "pixie_unet_forward: d_proj0 needs the hidden-128 projector (feature_channels > cond_dim)");
     PX_REQUIRE(d_feat || (d_proj0 && h->cfg.has_projector()), "pixie_unet_forward: d_feat is null");
     return guarded([&] {
-        const auto sized = size_pass(h, d, hh, w);
-        if (workspace_bytes < sized.first)
-            fail("pixie_unet_forward: workspace of %lld bytes, this grid needs %lld (pixie_unet_workspace_bytes)", (long long)workspace_bytes, (long long)sized.first);
+        const auto sized = size_pass(h, d, hh, w, d_proj0 != nullptr);
+        if (workspace_bytes < sized.bytes)
+            fail("pixie_unet_forward: workspace of %lld bytes, this grid needs %lld (pixie_unet_workspace_bytes)", (long long)workspace_bytes, (long long)sized.bytes);
         auto launch_all = [&] {
             Exec ex;
             ex.net = h; ex.dry = false; ex.stream = stream;
-            const int64_t slot_bytes = slot_region_bytes(sized.second);
+            const int64_t slot_bytes = slot_region_bytes(sized.slots), head_bytes = slot_bytes + zsum_region_bytes(sized.zsum_doubles);
             ex.slots = static_cast<uint32_t*>(d_workspace);
-            ex.slot_cap = sized.second;
-            if (hipMemsetAsync(d_workspace, 0, (size_t)slot_bytes, as_stream(stream)) != hipSuccess) fail("pixie_unet_forward: hipMemsetAsync failed");
-            ex.arena.reset(static_cast<char*>(d_workspace) + slot_bytes, workspace_bytes - slot_bytes);
+            ex.slot_cap = sized.slots;
+            ex.zsums = reinterpret_cast<double*>(static_cast<char*>(d_workspace) + slot_bytes);
+            ex.zsum_cap = sized.zsum_doubles;
+            if (hipMemsetAsync(d_workspace, 0, (size_t)head_bytes, as_stream(stream)) != hipSuccess) fail("pixie_unet_forward: hipMemsetAsync failed");
+            ex.arena.reset(static_cast<char*>(d_workspace) + head_bytes, workspace_bytes - head_bytes);
             TP out = ex.forward(d_feat, d_proj0, d, hh, w, d_out);
         };
         if (h->use_graph) {

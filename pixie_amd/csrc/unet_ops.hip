@@ -63,20 +63,23 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
 
 // mode 0: per-channel LayerNorm statistics (biased variance, eps inside the sqrt -- torch semantics)
 // mode 1: GroupNorm(groups): statistics over (channels/groups) x spatial, affine folded per channel
-__global__ void norm_finalize_kernel(const double* __restrict__ sums, int channels, double spatial, int mode, int groups, double eps,
-                                     const float* __restrict__ weight, const float* __restrict__ bias, float* __restrict__ a,
-                                     float* __restrict__ b) {
+// `sums` holds the first c0 channels, `sums1` (may be null) the channels from c0 on: the statistics of th.cat([h, skip]) are the
+// concatenation of the two tensors' statistics, read where they lie
+__global__ void norm_finalize_kernel(const double* __restrict__ sums, int c0, const double* __restrict__ sums1, int channels, double spatial,
+                                     int mode, int groups, double eps, const float* __restrict__ weight, const float* __restrict__ bias,
+                                     float* __restrict__ a, float* __restrict__ b) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= channels) return;
+    auto S = [&](int k, int which) { return k < c0 ? sums[2 * k + which] : sums1[2 * (k - c0) + which]; };
     double mean, var;
     if (mode == 0) {
-        mean = sums[2 * c] / spatial;
-        var = sums[2 * c + 1] / spatial - mean * mean;
+        mean = S(c, 0) / spatial;
+        var = S(c, 1) / spatial - mean * mean;
     } else {
         const int cpg = channels / groups;
         const int g = c / cpg;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s1 += sums[2 * k]; s2 += sums[2 * k + 1]; }
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s1 += S(k, 0); s2 += S(k, 1); }
         const double cnt = spatial * cpg;
         mean = s1 / cnt;
         var = s2 / cnt - mean * mean;
@@ -342,10 +345,10 @@ extern "C" int pixie_voxel_grid_to_ncdhw(const void* d_feat_dhwc_f16, int d, int
     return 0;
 }
 
-extern "C" int pixie_channel_stats(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, void* stream) {
-    PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_stats: bad arguments");
-    hipStream_t st = as_stream(stream);
-    PX_CHECK_HIP(hipMemsetAsync(d_sums, 0, (size_t)channels * 2 * sizeof(double), st));
+namespace pixie {
+// the launch of pixie_channel_stats for a d_sums the caller has already zeroed (csrc/unet_exec.hip zeroes all of a forward
+// pass's statistics buffers with one memset)
+int channel_stats_prezeroed(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, hipStream_t st) {
     // segments of >= 16 Ki elements, at most ~2048 blocks in total
     long splits = (spatial + 16383) / 16384;
     const long max_splits = std::max(1L, 2048L / channels);
@@ -358,6 +361,14 @@ extern "C" int pixie_channel_stats(const float* d_x, int channels, int64_t spati
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
+}  // namespace pixie
+
+extern "C" int pixie_channel_stats(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, void* stream) {
+    PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_stats: bad arguments");
+    hipStream_t st = as_stream(stream);
+    PX_CHECK_HIP(hipMemsetAsync(d_sums, 0, (size_t)channels * 2 * sizeof(double), st));
+    return pixie::channel_stats_prezeroed(d_x, channels, spatial, d_sums, d_amax, st);
+}
 
 extern "C" int pixie_channel_sums(const float* d_x, int channels, int64_t spatial, double* d_sums, void* stream) {
     return pixie_channel_stats(d_x, channels, spatial, d_sums, nullptr, stream);
@@ -367,11 +378,23 @@ extern "C" int pixie_norm_finalize(const double* d_sums, int channels, int64_t s
                                    const float* d_weight, const float* d_bias, float* d_a, float* d_b, void* stream) {
     PX_REQUIRE(d_sums && d_a && d_b && channels > 0 && spatial > 0, "pixie_norm_finalize: bad arguments");
     PX_REQUIRE(mode == 0 || (mode == 1 && groups > 0 && channels % groups == 0), "pixie_norm_finalize: bad mode/groups");
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(channels, 64)), dim3(64), 0, as_stream(stream), d_sums, channels, (double)spatial,
-                       mode, groups, eps, d_weight, d_bias, d_a, d_b);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(channels, 64)), dim3(64), 0, as_stream(stream), d_sums, channels,
+                       static_cast<const double*>(nullptr), channels, (double)spatial, mode, groups, eps, d_weight, d_bias, d_a, d_b);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+namespace pixie {
+// pixie_norm_finalize over the channel concatenation of two tensors' statistics (no copy of either)
+int norm_finalize_cat(const double* d_sums0, int c0, const double* d_sums1, int c1, int64_t spatial, int mode, int groups, double eps,
+                      const float* d_weight, const float* d_bias, float* d_a, float* d_b, hipStream_t st) {
+    const int channels = c0 + c1;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(channels, 64)), dim3(64), 0, st, d_sums0, c0, d_sums1, channels, (double)spatial, mode, groups,
+                       eps, d_weight, d_bias, d_a, d_b);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace pixie
 
 extern "C" int pixie_channel_affine(const float* d_x, const float* d_a, const float* d_b, float* d_y, int channels, int64_t spatial,
                                     void* stream) {
