@@ -181,11 +181,12 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     dt = max_over_ranks(time.perf_counter() - t0, world, device)
     flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
     # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution).  The timed region above is
-    # the product default: each network is ONE pixie_unet_forward call replayed as a captured HIP graph, the two networks on two
-    # HIP streams -- no per-launch events can be placed there.  The launch durations the roofline is computed from come from
-    # scenes run right after it through the Python plan walk (the same kernels, one foreign call per launch, HIP events around
-    # each): one scene on two streams (`avg_launch_ms_dual_stream`: an event pair around one network's launch also brackets
-    # whatever the other network had on the device) and two scenes on ONE stream (`avg_launch_ms`, the roofline's duration).
+    # the product default: each network is ONE pixie_unet_forward call replayed as a captured HIP graph, the two networks back
+    # to back on one stream -- no per-launch events can be placed inside a replay.  The launch durations the roofline is computed
+    # from come from scenes run right after it through the Python plan walk (the same kernels on the same stream, one foreign
+    # call per launch, HIP events around each): two scenes on ONE stream (`avg_launch_ms`, the roofline's duration; rocprofv3's
+    # per-kernel mean over the whole run, graph replays included, is the cross-check), and one scene with the networks on two
+    # streams (`avg_launch_ms_dual_stream`: an event pair then also brackets whatever the other network had on the device).
     for net in (seg, cont):
         net.executor, net.use_graph = "python", False
     step(dual_stream=False)                      # the plan walk packs its own copy of the weights
@@ -193,7 +194,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     prof.wrap(seg._runner.ops)   # one HipOps instance per network
     if cont._runner.ops is not seg._runner.ops:
         prof.wrap(cont._runner.ops)
-    step()
+    step(dual_stream=True)
     torch.cuda.synchronize()
     agg_timed = prof.summary()
     kernel_avg_timed = prof.by_variant()
@@ -510,7 +511,7 @@ def main():
                                    f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
                        "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
                        "weights": "seeded random init of the reference architecture",
-                       "executor": u["executor"] + " (one pixie_unet_forward call per network; two networks on two HIP streams)"},
+                       "executor": u["executor"] + " (one pixie_unet_forward call per network, the two networks back to back on one stream)"},
             "unet_tflops": u["flops_scene"] * world * u["steps"] / u["seconds"] / 1e12,
             "unet_conv_ms_per_step": u["conv_ms_per_step"],
             "roofline": u["roofline"],

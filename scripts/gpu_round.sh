@@ -48,12 +48,6 @@ echo "smoke exit $?" >> $OUT/smoke.log
 timeout 1200 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit $?" >> $OUT/bench.err
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --mpm-substeps 300 > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof_bench.err)
-# the same U-Net leg with the two networks on ONE stream: per-kernel durations undisturbed by the other network's kernels
-# (the row of conv3d_f16x3_c64_fullres_kernel is what bench.py's roofline.avg_launch_ms must agree with)
-(cd /tmp && PIXIE_DUAL_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof1 -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-mpm --no-shipped-shape > $ROOT/$OUT/prof_bench_single_stream.json 2> $ROOT/$OUT/prof_bench_single_stream.err)
-DB1=$(find $OUT/prof1 -name "*.db" | head -1)
-[ -n "$DB1" ] && python scripts/rocpd_stats.py $DB1 $OUT/kernel_stats_single_stream.csv
-rm -rf $OUT/prof1
 timeout 300 python scripts/unet_exec_bench.py 16 32 64 128 2>/dev/null | grep "D=" > $OUT/unet_exec_bench.txt
 bash scripts/gpu_conv_wino.sh $TAG > /dev/null 2>&1
 DB=$(find $OUT/prof -name "*.db" | head -1)
