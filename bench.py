@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-shipped-shape", action="store_true", help="skip the 64^3 x 768 fp16-grid sub-record")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32-MFMA sub-record of the same U-Net step")
     ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
+    ap.add_argument("--dual-stream-diagnostic", action="store_true",
+                    help="also time one scene's launches with the two networks on two HIP streams (roofline.avg_launch_ms_dual_stream)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
                     help="torch.distributed backend for --gpus N > 1 (default nccl = RCCL over xGMI; gloo only for --launcher-selftest)")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -185,8 +187,8 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     # to back on one stream -- no per-launch events can be placed inside a replay.  The launch durations the roofline is computed
     # from come from scenes run right after it through the Python plan walk (the same kernels on the same stream, one foreign
     # call per launch, HIP events around each): two scenes on ONE stream (`avg_launch_ms`, the roofline's duration; rocprofv3's
-    # per-kernel mean over the whole run, graph replays included, is the cross-check), and one scene with the networks on two
-    # streams (`avg_launch_ms_dual_stream`: an event pair then also brackets whatever the other network had on the device).
+    # per-kernel mean over the whole run, graph replays included, is the cross-check).  --dual-stream-diagnostic adds one scene
+    # with the networks on two streams (`avg_launch_ms_dual_stream`: an event pair then also brackets the other network's kernels).
     for net in (seg, cont):
         net.executor, net.use_graph = "python", False
     step(dual_stream=False)                      # the plan walk packs its own copy of the weights
@@ -194,11 +196,13 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     prof.wrap(seg._runner.ops)   # one HipOps instance per network
     if cont._runner.ops is not seg._runner.ops:
         prof.wrap(cont._runner.ops)
-    step(dual_stream=True)
-    torch.cuda.synchronize()
-    agg_timed = prof.summary()
-    kernel_avg_timed = prof.by_variant()
-    prof.records.clear(); prof.variants.clear()
+    agg_timed, kernel_avg_timed = {}, None
+    if args.dual_stream_diagnostic:   # off by default: its overlapped launches would pollute rocprofv3's per-kernel means of this command
+        step(dual_stream=True)
+        torch.cuda.synchronize()
+        agg_timed = prof.summary()
+        kernel_avg_timed = prof.by_variant()
+        prof.records.clear(); prof.variants.clear()
     for _ in range(2):
         step(dual_stream=False)
     agg = prof.summary()
@@ -511,7 +515,7 @@ def main():
                                    f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
                        "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
                        "weights": "seeded random init of the reference architecture",
-                       "executor": u["executor"] + " (one pixie_unet_forward call per network, the two networks back to back on one stream)"},
+                       "executor": u["executor"] + " (one pixie_unet_forward call per network; graph replays of >= 128^3 grids run back to back on one stream)"},
             "unet_tflops": u["flops_scene"] * world * u["steps"] / u["seconds"] / 1e12,
             "unet_conv_ms_per_step": u["conv_ms_per_step"],
             "roofline": u["roofline"],
@@ -537,7 +541,8 @@ def main():
         line["layer_ms_top"] = u["layer_ms"]
         # per kernel NAME, all shapes pooled: comparable with the avg column of profiles/*_kernel_stats.csv (rocprofv3 --stats)
         line["conv_kernel_avg_ms"] = u["kernel_avg"]                           # single-stream pass
-        line["conv_kernel_avg_ms_dual_stream"] = u["kernel_avg_timed"]        # two streams: launches of the two networks overlap
+        if u["kernel_avg_timed"] is not None:
+            line["conv_kernel_avg_ms_dual_stream"] = u["kernel_avg_timed"]    # two streams: launches of the two networks overlap
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

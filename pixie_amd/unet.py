@@ -680,7 +680,7 @@ def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont
     packed = [(net._runner._w16(q), net._runner._b(q)) for net in nets]
     x_seg, x_cont = ops.projector_conv0(g, packed, seg_network.cfg.projector_hidden)
     if dual_stream is None:
-        dual_stream = _dual_stream_default(seg_network, cont_network)
+        dual_stream = _dual_stream_default(seg_network, cont_network, int(g.shape[0]) * int(g.shape[1]) * int(g.shape[2]))
 
     def fwd(net, p0):
         return net._forward_graphed(None, p0) if net.use_graph else net._forward_one(None, proj0=p0)
@@ -706,15 +706,15 @@ def predict_material_field_from_voxel_grid(seg_network: "SegmentationUNet", cont
 _SIDE_STREAMS: Dict[str, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
-def _dual_stream_default(seg_network, cont_network) -> bool:
-    """The two networks are independent.  Launched eagerly, putting them on two HIP streams lets one network's small kernels
-    and kernel tails fill the CUs the other leaves idle (measured 94.7 -> 89.6 ms per 128^3 scene).  Replayed as HIP graphs
-    (the default) there are no launch gaps left to fill and two graphs only contend for the chip (measured on one box:
-    89.0 ms on two streams, 85.5-87.1 ms back to back), so graphs run back to back.  PIXIE_DUAL_STREAM=0/1 overrides."""
+def _dual_stream_default(seg_network, cont_network, voxels: int) -> bool:
+    """The two networks are independent: on two HIP streams one network's small kernels and kernel tails fill the CUs the other
+    leaves idle (eager launches at 128^3: 94.7 -> 89.6 ms per scene; graph replays at 64^3: 17.0 -> 15.2 ms).  The exception is
+    large grids replayed as HIP graphs: every launch fills the chip, there are no launch gaps left to fill, and two graphs only
+    contend (128^3, one box: 89.0 ms on two streams, 85.5-87.1 ms back to back).  PIXIE_DUAL_STREAM=0/1 overrides."""
     env = os.environ.get("PIXIE_DUAL_STREAM")
     if env is not None:
         return env == "1"
-    return not (seg_network.use_graph and cont_network.use_graph)
+    return not (seg_network.use_graph and cont_network.use_graph and voxels >= 128 ** 3)
 
 
 def _side_streams(device):
@@ -729,9 +729,9 @@ def predict_material_field(seg_network: SegmentationUNet, cont_network: Regressi
                            dual_stream: Optional[bool] = None):
     """The compute of process_batch + save_predictions (trainer/inference_combined.py:122-126,186-195):
     returns (combined (N, 3+num_classes, D, H, W), seg_pred (N, D, H, W) int32, seg_logits, cont_pred).
-    `dual_stream`: the two networks on two HIP streams; default = only when they are launched eagerly (_dual_stream_default)."""
+    `dual_stream`: the two networks on two HIP streams; default: see _dual_stream_default."""
     if dual_stream is None:
-        dual_stream = _dual_stream_default(seg_network, cont_network)
+        dual_stream = _dual_stream_default(seg_network, cont_network, int(feat_grid[0, 0].numel()))
     if dual_stream and feat_grid.is_cuda:
         # the two networks are independent: run them on two HIP streams so that one network's small kernels and
         # kernel tails fill the CUs the other leaves idle
