@@ -611,7 +611,8 @@ class _PixieUNet(nn.Module):
         packs the weights and takes the host-side parameter bounds -- and replayed with a single hipGraphLaunch: the device
         runs the kernels back to back and the host queues one launch.  Returns a copy of the graph's static output."""
         src = proj0 if proj0 is not None else x
-        key = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index, tuple(p._version for p in self.parameters()))
+        key = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index,
+               tuple((p.data_ptr(), p._version) for p in self.parameters()))   # storage AND version: `p.data = t` / `.to()` keep the version
         run = (lambda t: self._forward_one(None, proj0=t)) if proj0 is not None else (lambda t: self._forward_one(t))
         ent = self._graphs.get(key)
         if ent is None:
