@@ -95,12 +95,9 @@ def test_phase_by_phase_parity(hip_device):
     assert h.out_of_bounds == 0
 
 
-@pytest.mark.parametrize("scenario,steps", [("tree", 200), ("ball", 200)])
-def test_rollout_parity(hip_device, scenario, steps):
-    sc = mpm_ball_scene(20000, seed=2, scenario=scenario)
-    h, o32, o64 = make_hip(sc), make_oracle(sc, "f32"), make_oracle(sc, "f64")
-    h.run(sc["dt"], steps)
-    o32.run(sc["dt"], steps); o64.run(sc["dt"], steps)
+def _assert_rollout_parity(h, o32, o64, sc, tag):
+    """x and F_trial within 1e-4 of the float64 oracle outright; displacement, v and C within max(1e-4, 4 x the float32
+    oracle's own distance from the float64 oracle)."""
     assert abs(h.time - o64.time) < 1e-12
     x_h, F_h, v_h, C_h = get(h, "x"), get(h, "F_trial").reshape(-1, 3, 3), get(h, "v"), get(h, "C").reshape(-1, 3, 3)
     assert np.isfinite(x_h).all()
@@ -118,9 +115,30 @@ def test_rollout_parity(hip_device, scenario, steps):
     for name, got, scale in (("v", v_h, v_rms), ("C", C_h, max(v_rms * inv_dx, float(np.linalg.norm(o64.field("C")) / np.sqrt(n))))):
         drift = float(np.linalg.norm(o32.field(name).astype(np.float64) - o64.field(name)) / np.sqrt(n)) / scale
         err = float(np.linalg.norm(got.astype(np.float64) - o64.field(name)) / np.sqrt(n)) / scale
-        print(f"{scenario} {name}: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  (scale {scale:.3e})")
+        print(f"{tag} {name}: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  (scale {scale:.3e})")
         assert err < max(1e-4, 4 * drift)
     assert h.out_of_bounds == 0
+
+
+@pytest.mark.parametrize("scenario,steps", [("tree", 200), ("ball", 200)])
+def test_rollout_parity(hip_device, scenario, steps):
+    sc = mpm_ball_scene(20000, seed=2, scenario=scenario)
+    h, o32, o64 = make_hip(sc), make_oracle(sc, "f32"), make_oracle(sc, "f64")
+    h.run(sc["dt"], steps)
+    o32.run(sc["dt"], steps); o64.run(sc["dt"], steps)
+    _assert_rollout_parity(h, o32, o64, sc, scenario)
+
+
+def test_rollout_parity_at_the_1m_bench_size(hip_device):
+    """The scene bench.py's `mpm_1m` leg times -- BASELINE configs[4]'s per-GPU MPM workload: 1 000 000 particles, n_grid 120,
+    tree scenario -- for 20 substeps against the scalar C oracle in float32 and float64 (2 x ~25 s of one host core): the
+    multi-item blocks, the 5555-item work list and the 120^3 block tables of the full-size run, not a scaled-down stand-in."""
+    sc = mpm_ball_scene(1_000_000, seed=0, n_grid=120)
+    h, o32, o64 = make_hip(sc), make_oracle(sc, "f32"), make_oracle(sc, "f64")
+    h.run(sc["dt"], 20)
+    o32.run(sc["dt"], 20); o64.run(sc["dt"], 20)
+    _assert_rollout_parity(h, o32, o64, sc, "1M")
+    assert int(h._get_scalar("n_work_items")) > 4000
 
 
 def test_fast_particles_drift_controller_and_slow_path(hip_device):
