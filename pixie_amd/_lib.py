@@ -153,6 +153,11 @@ def load():
         raise PixieHipError(
             f"{LIB_PATH} not found: build it with `python -m pixie_amd.build` (hipcc, gfx950). "
             "pixie_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  The process must have ONE HIP runtime -- streams and
+    # device pointers cross the C ABI in both directions -- so torch's copy has to be in the process before ours is resolved
+    # (same SONAME: the loader then binds libpixie_hip.so to it).  Loaded the other way round, the system ROCm runtime and
+    # torch's coexist and the first hipMalloc / launch on a torch stream fails.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -77,3 +77,17 @@ def test_reference_material_name_quirk():
     from pixie_amd.mpm_solver import NAME_TO_MATERIAL_ID, get_material_id, get_material_name
     assert get_material_name("sand") == 2 and get_material_name("visplas") == -1 and get_material_id("snow") == 5
     assert NAME_TO_MATERIAL_ID["stationary"] == 6 and "fluid" not in NAME_TO_MATERIAL_ID
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """Loading the library before torch must not leave two HIP runtimes in the process (torch's bundled libamdhip64 and the
+    system ROCm one): build() followed by smoke() in one process broke exactly that way."""
+    import subprocess
+    import sys
+    code = ("from pixie_amd import _lib; _lib.load(); import torch;"
+            "m = open('/proc/self/maps').read();"
+            "libs = sorted({l.split()[-1] for l in m.splitlines() if 'libamdhip64' in l});"
+            "print(len(libs)); print(libs)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == "1", out.stdout
