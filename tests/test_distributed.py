@@ -80,3 +80,38 @@ def test_bench_self_launch_gloo_world2():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["world"] == 2 and rec["collective_ranks"] == 2 and rec["backend"] == "gloo" and rec["gather_ok"]
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_and_graph_capture_coexist(hip_device):
+    """A live RCCL process group (communicator, watchdog thread) while the U-Net forward is captured into HIP graphs and
+    replayed between collectives -- the order of operations of `bench.py --gpus N` on each rank.  World size 1 (one GPU on the
+    test box): what is exercised is RCCL and graph capture sharing a process, not the wire."""
+    import socket
+
+    import torch.distributed as dist
+    from pixie_amd.synthetic import feature_grid
+    from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
+    from pixie_amd.unet_plan import synthetic_state_dict
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        t = torch.ones(8, device=hip_device)
+        dist.all_reduce(t)                                        # creates the communicator and starts the watchdog
+        kw = dict(feature_channels=64, cond_dim=32, model_channels=32, num_res_blocks=1, channel_mult=(1, 2), attention_resolutions=(), grid_size=16)
+        seg, cont = SegmentationUNet(num_classes=8, **kw), RegressionUNet(out_channels=3, **kw)
+        seg.load_numpy_state(synthetic_state_dict(seg.cfg, 3)); cont.load_numpy_state(synthetic_state_dict(cont.cfg, 4))
+        seg, cont = seg.to(hip_device).eval(), cont.to(hip_device).eval()
+        feat = torch.from_numpy(feature_grid(16, 64, seed=5)).to(hip_device)
+        seg.use_graph = cont.use_graph = False
+        want = predict_material_field(seg, cont, feat)[0]
+        seg.use_graph = cont.use_graph = True
+        for _ in range(3):                                        # capture (first pass), then replays, a collective after each
+            combined, seg_pred, _, cont_pred = predict_material_field(seg, cont, feat)
+            gathered = torch.empty_like(cont_pred)
+            dist.all_gather_into_tensor(gathered, cont_pred.contiguous())
+            dist.barrier()
+            assert torch.equal(combined, want) and torch.equal(gathered, cont_pred)
+        assert seg.use_graph and cont.use_graph                   # the capture did not fall back to eager launches
+    finally:
+        dist.destroy_process_group()
