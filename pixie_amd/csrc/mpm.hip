@@ -1266,8 +1266,10 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
     // Cadence: the LDS tile tolerates one cell of drift, and the measured drift of the interval just finished
-    // predicts the next one -- aim at 0.4 cells, never more than double, and halve when > 0.1 % of the particles
-    // were on the slow path.  (The host enqueues substeps far ahead of the device, so this is the only feedback.)
+    // predicts the next one -- aim at 0.4 cells, never more than four times the last interval (a re-binning of 1 M
+    // particles costs ~0.4 ms = 4 substeps: with doubling, the ramp 4, 8, ..., 256 of a quiet scene spent six of them in
+    // the first 252 substeps), and halve when > 0.1 % of the particles were on the slow path.  (The host enqueues substeps
+    // far ahead of the device, so this is the only feedback.)
     if (h->resort_auto) {
         unsigned long long slow_total;
         memcpy(&slow_total, h->h_n_items + 4, sizeof slow_total);
@@ -1278,8 +1280,8 @@ int rebin(pixie_mpm* h, hipStream_t st) {
         const double drift_cells = sqrt((double)d2) * (double)S.inv_dx;
         if (h->n_sorts > 0 && h->xref_valid) {
             int k = h->resort_interval;
-            if (drift_cells > 0.0) k = (int)std::min<double>(2.0 * k, std::max<double>(0.25 * k, k * 0.4 / drift_cells));
-            else k = 2 * k;
+            if (drift_cells > 0.0) k = (int)std::min<double>(4.0 * k, std::max<double>(0.25 * k, k * 0.4 / drift_cells));
+            else k = 4 * k;
             if (since > (unsigned long long)n / 1000) k = std::min(k, h->resort_interval / 2);
             h->resort_interval = std::max(2, std::min(k, 256));
         }
