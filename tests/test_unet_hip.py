@@ -470,7 +470,7 @@ def test_network_matches_reference_golden(hip_device, name, precision):
         model.conv_precision = precision
         taps = {}
         y = model(feat, taps).cpu().numpy()        # `taps` selects the Python plan walk (one foreign call per operator)
-        assert model.executor == "c"
+        model.executor = "c"                       # (the default, unless PIXIE_UNET_EXECUTOR says otherwise)
         y_handle = model(feat).cpu().numpy()       # the product default: pixie_unet_forward, one foreign call per network
         assert np.array_equal(y_handle, y), f"{name}/{head}/{precision}: the C executor and the Python plan walk differ"
         err = rel_l2(y, g[head])
@@ -499,6 +499,7 @@ def test_unet_handle_follows_parameter_updates_and_rejects_bad_calls(hip_device)
                            kw["attention_resolutions"], kw["grid_size"], 3)
     model.load_numpy_state(synthetic_state_dict(model.cfg, wseed))
     model = model.to(hip_device).eval()
+    model.conv_precision, model.executor = "f16x3", "c"
     feat = torch.from_numpy(feature_grid(kw["grid_size"], kw["feature_channels"], seed=iseed)).to(hip_device)
     y0 = model(feat)
     with torch.no_grad():
@@ -545,7 +546,7 @@ def test_unet_handle_replays_its_own_hip_graph(hip_device):
                              kw["attention_resolutions"], kw["grid_size"], 8)
     model.load_numpy_state(synthetic_state_dict(model.cfg, wseed))
     model = model.to(hip_device).eval()
-    model.use_graph = False
+    model.use_graph, model.conv_precision, model.executor = False, "f16x3", "c"
     D = kw["grid_size"]
     feats = [torch.from_numpy(feature_grid(D, kw["feature_channels"], seed=iseed + i)).to(hip_device)[0].contiguous() for i in range(3)]
     eager = [model(f[None])[0] for f in feats]
@@ -739,6 +740,7 @@ def test_fused_voxel_grid_path(hip_device, C, D):
     sd_s, sd_c = synthetic_state_dict(seg.cfg, 21), synthetic_state_dict(cont.cfg, 22)
     seg.load_numpy_state(sd_s); cont.load_numpy_state(sd_c)
     seg, cont = seg.to(hip_device).eval(), cont.to(hip_device).eval()
+    seg.conv_precision = cont.conv_precision = "f16x3"   # the fused route exists on the f16x3 path only
     g_dev = torch.from_numpy(grid).to(hip_device)
     # (a) the operator
     ops = HipOps(hip_device)
