@@ -6,11 +6,14 @@ trainer/training_continuous_mse.py:48-89) around FeatureProjector + MyUNetModel
 (models/module/diffusion_network.py:534-589, :712-935), so `create_models` / `load_checkpoint` /
 `process_batch` of trainer/inference_combined.py:81-126 work unchanged.
 
-Execution model: the network is walked as a flat plan (pixie_amd/unet_plan.py) and every layer is
-one call into the C ABI.  Each convolution consumes its normalisation + activation as a fused
-prologue and its residual as a fused epilogue, `th.cat` and nearest-upsampling are index maths inside
-the conv kernel, so the only tensors that touch HBM are conv outputs.  Host code (this file) only
-sequences launches on the current stream; there is no CPU implementation of any operator here.
+Execution model: a network's forward pass is ONE call into the C ABI -- pixie_unet_forward (csrc/unet_exec.hip) owns the plan,
+the workspace placement and the ~400-launch sequence -- replayed as a captured HIP graph by default (UNetHandle,
+_PixieUNet._forward_graphed).  UNetRunner + HipOps below walk the same plan (pixie_amd/unet_plan.py) from Python with one
+foreign call per operator: bit-identical, kept for the per-block `taps` hook and for the CPU wiring tests (which inject torch
+stand-ins for the operators).  Either way each convolution consumes its normalisation + activation as a fused prologue and its
+residual (and, where channel counts change, the block's 1x1x1 skip convolution) as a fused epilogue, `th.cat` and
+nearest-upsampling are index maths inside the conv kernel, so the only tensors that touch HBM are conv outputs.  Host code
+(this file) only sequences launches on the current stream; there is no CPU implementation of any operator here.
 """
 from __future__ import annotations
 
