@@ -23,4 +23,9 @@ for k, v in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:4]:
     v2 = sorted(v)
     print(f"gap {k:80s} n={len(v):5d}  mean {sum(v) / len(v):6.2f} us  median {v2[len(v2) // 2]:6.2f} us")
 span = (rows[-1][2] - rows[0][1]) / 1e3
-print(f"span {span:.1f} us over {len(rows)} dispatches")
+busy = sum((e - s_) / 1e3 for _, s_, e in rows)
+allgaps = [(b[1] - a[2]) / 1e3 for a, b in zip(rows, rows[1:])]
+pos = sorted(g for g in allgaps if g > 0)
+print(f"span {span:.1f} us over {len(rows)} dispatches; kernels busy {busy:.1f} us ({100 * busy / span:.1f} %); "
+      f"gaps: mean {sum(allgaps) / max(len(allgaps), 1):.2f} us, median {sorted(allgaps)[len(allgaps) // 2]:.2f} us, "
+      f"p90 {sorted(allgaps)[int(0.9 * len(allgaps))]:.2f} us")
