@@ -68,6 +68,12 @@ struct MpmPtrs {
     const int2* nbr_table;       // per active block (same order): [0] = (block id, 0), [1..27] = blk_items of its 27 neighbours
     unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles,
                                  // [2] slow-path particles dropped because they had left every active block
+    // ---- grid update in the tail of the block kernel (F_TAIL): see grid_tail()
+    float4* gout_next;           // the grid-velocity array the tail writes (ping-pong partner of gout)
+    int* arrive;                 // per active block: work items that have published a tile covering it (reset by the last one)
+    const int* expected;         // per active block: work items of its 27 neighbours = arrivals that complete it
+    const int* blk_slot;         // per block: its position in active_list / nbr_table (-1: inactive)
+    const int* nbr_slots;        // per active block: blk_slot of its 27 neighbours (-1: outside the grid)
 };
 
 struct StepParams {
@@ -168,7 +174,9 @@ __device__ __forceinline__ void weights_1d(const Stencil& st, int d, Weights1D& 
 }
 
 // v = sum w g;  B_ab = sum w g_a dpos_b (cell units);  G_ab = sum g_a dweight_b (cell units)
-template <class Fetch>
+// SCHED: keep the loads of one x-slab from being hoisted over the previous slab's arithmetic (the 5-waves-per-SIMD register
+// budget needs it; the wide variant for small scenes, F_WIDE, lets the compiler overlap everything).
+template <bool SCHED, class Fetch>
 __device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float nv[3], Mat3& B, Mat3& G) {
     Weights1D wx, wy, wz;
     weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
@@ -212,13 +220,13 @@ __device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float
             G.m[3 * a + 2] = fmaf(wx.w[i], sd[a], G.m[3 * a + 2]);
             B.m[3 * a + 2] = fmaf(wx.w[i], sz[a], B.m[3 * a + 2]);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the 27 loads of the next x-slab from being hoisted over this one
+        if (SCHED) __builtin_amdgcn_sched_barrier(0);  // keep the 27 loads of the next x-slab from being hoisted over this one
     }
 }
 
 // momentum_a(i,j,k) = w (mv_a + A_a . dpos) + T_a . gradw,  mass(i,j,k) = w m   with A = m C' dx (dpos in cell
 // units) and T = -dt vol inv_dx tau (gradw in cell units)
-template <class Emit>
+template <bool SCHED, class Emit>
 __device__ __forceinline__ void p2g_scatter(const Stencil& st, const float mv[3], const Mat3& A, const Mat3& T, float mass, Emit emit) {
     Weights1D wx, wy, wz;
     weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
@@ -251,7 +259,7 @@ __device__ __forceinline__ void p2g_scatter(const Stencil& st, const float mv[3]
                 emit(i, j, k, mom, wz.w[k] * M);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (SCHED) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -283,15 +291,21 @@ __device__ __noinline__ void g2p_gather_global(const float4* __restrict__ gout, 
 }
 
 __device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int nbk, int ng, Stencil st,
-                                                const float* mvAT /* mv[3], A[9], T[9] */, float mass) {
+                                                const float* mvAT /* mv[3], A[9], T[9] */, float mass, int own_block) {
     const size_t r0 = ((size_t)st.base[0] * ng + st.base[1]) * ng + st.base[2];
     // the 3x3x3 stencil touches at most 2 blocks per axis: tell the grid kernel they hold gin contributions.  The grid
     // kernel only visits ACTIVE blocks (particles within one block at the last re-binning); a particle that has left
     // all of them drifted >= 3 cells since then although the re-binning cadence is set to keep the drift below half a
     // cell (rebin()) -- it is dropped and counted, like a particle that leaves the grid.
+    // With the grid update in the block kernel's tail (own_block >= 0) the node blocks written here must also be among
+    // the 27 neighbours of this work item's block: only those wait for this item's arrival before they are reduced.
     bool reachable = true;
     for (int c = 0; c < 8; ++c) {
         const int bx = (st.base[0] + 2 * (c >> 2)) / kBS, by = (st.base[1] + 2 * ((c >> 1) & 1)) / kBS, bz = (st.base[2] + 2 * (c & 1)) / kBS;
+        if (own_block >= 0) {
+            const int oz = own_block % nbk, oy = (own_block / nbk) % nbk, ox = own_block / (nbk * nbk);
+            if (abs(bx - ox) > 1 || abs(by - oy) > 1 || abs(bz - oz) > 1) { reachable = false; continue; }
+        }
         reachable = reachable && (atomicOr(&blk_flags[(bx * nbk + by) * nbk + bz], 2) & 1);
     }
     if (!reachable) return false;
@@ -356,7 +370,7 @@ __device__ __forceinline__ void preload_particle(const MpmPtrs& S, int p, Preloa
     }
 }
 
-template <bool DO_G2P, bool DO_P2G>
+template <bool DO_G2P, bool DO_P2G, bool SCHED>
 __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
                                                 int oz, const float4* tv, const Preload& L, ScatterIn& out) {
     out.active = false;
@@ -380,7 +394,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
         if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
             const int b0 = (lx * kTS + ly) * kTS + lz;
-            g2p_gather(st, [&](int i, int j, int k, float g[3]) {
+            g2p_gather<SCHED>(st, [&](int i, int j, int k, float g[3]) {
                 // One ds_read_b128 per node.  The .w lane is dead, but a 16-byte LDS read costs 4 LDS cycles per wave against
                 // 8 for the 12-byte ds_read_b96 the compiler would narrow it to (MI355X_MICROARCH.md, LDS table), and LDS
                 // and VALU time add up in this kernel (80.7 -> 78.4 us per launch at 1 M particles): keep the lane alive.
@@ -472,46 +486,113 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
     }
 }
 
-// 64-bit fixed point through the double-precision adder: the mantissa field of (x + 1.5 * 2^52) is 2^51 + round(x) for
-// |x| < 2^51, so ds_add_u64 of the raw bit patterns accumulates sum(round(x_i)) modulo 2^51 in the low 51 bits whatever
-// happens above them (the N copies of the exponent and of the 2^51 offset only carry upwards).  With every contribution
-// scaled below 2^42 and at most 256 of them per node the sum stays below 2^50 and is recovered by sign-extending bit 50:
-// two instructions per contribution (v_cvt_f64_f32, v_add_f64), exact integer accumulation, order-independent.
+// ---- fixed-point accumulation of the scatter ---------------------------------------------------------------------------
+// EXACT mode (default): 64-bit fixed point through the double-precision adder: the mantissa field of (x + 1.5 * 2^52) is
+// 2^51 + round(x) for |x| < 2^51, so ds_add_u64 of the raw bit patterns accumulates sum(round(x_i)) modulo 2^51 in the low
+// 51 bits whatever happens above them (the N copies of the exponent and of the 2^51 offset only carry upwards).  With every
+// contribution scaled below 2^42 and at most 256 of them per node the sum stays below 2^50 and is recovered by
+// sign-extending bit 50: two instructions per contribution (v_cvt_f64_f32, v_add_f64), exact integer accumulation,
+// order-independent.
+// PACKED mode (F_PACK32, set_scalar "scatter_bits" 32): two 32-bit two's-complement integers per ds_add_u64 -- (m*v.x, m*v.y)
+// and (m, m*v.z) -- so a node costs 2 LDS atomics instead of 4 and 6 plain VALU instructions instead of 8 double-rate ones.
+// Every contribution is scaled below 2^22 (sums of 256 stay below 2^30) and rounded to nearest by v_cvt_rpi_i32_f32; the
+// pair word is low + (high << 32) in 64-bit arithmetic, i.e. the high dword carries `high + (low >> 31)`, and the decode
+// undoes exactly that, so the two sums are exact integers and order-independent like the 64-bit ones.  What changes is the
+// quantum: 2^-22 of the largest contribution bound in the tile instead of 2^-42 -- the same order as the fp32 atomics of the
+// reference (2^-24 of each partial sum) for nodes that carry mass, but a node whose whole mass is below ~1e-6 of a
+// particle's (stencil corners at a free surface) is quantised visibly: see DESIGN.md 3.5 and
+// tests/test_mpm_hip.py::test_packed_scatter_parity.
 constexpr double kMagicD = 6755399441055744.0;            // 1.5 * 2^52
 
-// power of two s with bound * s in [2^41, 2^42)  (1 when the bound is zero / not finite)
-__device__ __forceinline__ float scale_for(float bound) {
+// power of two s with bound * s in [2^top, 2^(top+1))  (1 when the bound is zero / not finite)
+__device__ __forceinline__ float scale_for(float bound, int top) {
     const unsigned bits = __float_as_uint(bound);
     const int eb = (int)((bits >> 23) & 0xffu) - 127;
     if (!(bound > 0.0f) || eb > 120) return 1.0f;
-    int e = 41 - eb;
+    int e = top - eb;
     e = e > 120 ? 120 : (e < -80 ? -80 : e);
     return __uint_as_float((unsigned)(e + 127) << 23);
 }
 __device__ __forceinline__ unsigned long long to_fixed(float scaled) {
     return (unsigned long long)__double_as_longlong((double)scaled + kMagicD);
 }
+// low 51 bits, sign-extended, as a float: flipping bit 50 turns the field into (sum + 2^50) >= 0, which is dropped into the
+// mantissa of 2^52 and the two offsets subtracted again -- exact (|sum| < 2^50), and no 64-bit integer conversion
 __device__ __forceinline__ float from_fixed(unsigned long long v, float inv_scale) {
-    const long long x = (long long)(v << 13) >> 13;      // low 51 bits, sign-extended
-    return (float)((double)x * (double)inv_scale);
+    const unsigned hi = (((unsigned)(v >> 32) & 0x7ffffu) ^ 0x40000u) | 0x43300000u;
+    const double d = __hiloint2double((int)hi, (int)(unsigned)v) - 5629499534213120.0;   // 2^52 + 2^50
+    return (float)(d * (double)inv_scale);
+}
+__device__ __forceinline__ int round_to_int(float x) {   // floor(x + 0.5): one instruction (CDNA keeps GCN's v_cvt_rpi)
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned long long pack_pair(int low, int high) {
+    return (unsigned long long)(unsigned)low | ((unsigned long long)(unsigned)(high + (low >> 31)) << 32);
+}
+__device__ __forceinline__ void unpack_pair(unsigned long long w, int& low, int& high) {
+    low = (int)(unsigned)w;
+    high = (int)(unsigned)(w >> 32) - (low >> 31);
+}
+
+// Maximum of a non-negative float over the wave, in the DPP network (no LDS round trips: __shfl_xor is ds_bpermute, six
+// dependent ~60-cycle LDS operations per value).  Non-negative floats order like their bit patterns, so the maximum is
+// taken on integers (no NaN canonicalisation instructions; a NaN bound comes out as the maximum, which scale_for maps to 1).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+    // lanes the pattern does not feed (masked rows) read their own value: old = v, bound_ctrl off
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return max(v, o);
+}
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+    unsigned v = __float_as_uint(x);
+    v = dpp_umax<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v = dpp_umax<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v = dpp_umax<0x141, 0xf>(v);    // row_half_mirror
+    v = dpp_umax<0x140, 0xf>(v);    // row_mirror: every lane of a row of 16 holds the row maximum
+    v = dpp_umax<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_umax<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave maximum
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v, 63));
 }
 
 // Phase trace (pixie_mpm_set_scalar "trace" 1; read back with pixie::mpm_trace_read, not part of the C ABI): per work item 8
 // 100 MHz timestamps -- start, tile staged, particles updated (G2P + stress), scales known, scatter done, tile published.
 constexpr int kMpmTraceItems = 32768;
 __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
-#define PX_MPM_STAMP(i) do { if (DO_G2P && DO_P2G && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define PX_MPM_STAMP(i) do { if ((FL & F_TRACE) && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+
+// kernel variants (FL)
+constexpr int F_TRACE = 1;    // phase stamps + the ablation switches of StepParams.trace (timing studies only)
+constexpr int F_PACK32 = 2;   // packed 32-bit scatter (above)
+constexpr int F_TAIL = 4;     // grid update in the kernel's tail (grid_tail below): ONE launch per substep
+constexpr int F_WIDE = 8;     // no scheduling barriers: for scenes too small to fill the chip, where latency, not issue, binds
+
+template <int RB, bool SC>
+__device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, int slot, float4* dst);
+
+// 16-byte store that is written through to memory (sc0 sc1): what another CU's sc0 sc1 load is guaranteed to see once this
+// wave's vmcnt has drained -- no L2 write-back fence needed (MI355X_MICROARCH.md, inter-workgroup visibility)
+__device__ __forceinline__ void store_through(float4* p, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(w) : "memory");
+}
 
 // OCC = waves per SIMD the register allocation is held to (launch_bounds).  Built without the SLP vectoriser (see
 // pixie_amd/build.py) the kernel needs 96 VGPRs -> 5 waves per SIMD with no spills (with it: 168 VGPRs, 3 waves, and
 // 20 % slower); 6 -> 80 VGPRs with ~20 spilled dwords (measured slower: 86 vs 81 us at 1 M particles).  Chosen at run
 // time (set_scalar "occupancy"), same arithmetic.
-template <bool DO_G2P, bool DO_P2G, int OCC>
-__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
+template <bool DO_G2P, bool DO_P2G, int OCC, int FL>
+__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms, BCSet bcs) {
+    constexpr bool PACK = (FL & F_PACK32) != 0;
+    constexpr bool TRACE = (FL & F_TRACE) != 0;
+    constexpr bool TAIL = (FL & F_TAIL) != 0;
+    constexpr bool SCHED = (FL & F_WIDE) == 0;
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
-    __shared__ unsigned long long ta[4][kTN];  // (m*v.xyz, m) of this work item as scaled 64-bit integers (P2G target)
+    __shared__ unsigned long long ta[PACK ? 2 : 4][kTN];  // (m*v.xyz, m) of this work item as scaled integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
-    __shared__ float4 tf[kTN];    // running fp32 tile of a multi-chunk work item
+    __shared__ int s_done;
     const int4 it = S.items[blockIdx.x];
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;   // = the work-item capacity of the current binning (256; 128 on request)
@@ -522,63 +603,64 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     Preload L;
     L.selection = 1;
     if (tid < it.z) preload_particle<DO_G2P, DO_P2G>(S, it.y + tid, L);   // in flight while the tile is staged
+    if (TAIL && tid == 0) s_done = 0;
     for (int idx = tid; idx < kTN; idx += nthr) {
         if (DO_G2P) {
             const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng && !(sp.trace & 0x400))
+            if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng && !(TRACE && (sp.trace & 0x400)))
                 g = S.gout[((size_t)gx * ng + gy) * ng + gz];
             tv[idx] = g;
         }
-        if (DO_P2G) { ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
+        if (DO_P2G) {
+            ta[0][idx] = 0ull; ta[1][idx] = 0ull;
+            if (!PACK) { ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
+        }
     }
     __syncthreads();
     PX_MPM_STAMP(1);
 
     // One chunk of <= 256 particles per work item.  Sharing one tile between more particles was measured both ways and
-    // loses: (a) a workgroup looping over several 256-particle chunks (integer sums folded into an fp32 tile tf between
+    // loses: (a) a workgroup looping over several 256-particle chunks (integer sums folded into an fp32 tile between
     // chunks) -- hipcc 7.2 keeps 176 VGPRs live across the loop (3 waves per SIMD instead of 5); (b) work items of 384 ...
     // 1024 threads -- 107 ... 132 us per launch at 1 M particles against 81 us for 256 (r2g): every barrier then waits
     // for the slowest of 6 ... 16 waves.  The per-item costs (staging, zeroing, publish) are the smaller evil.
-    constexpr int nchunks = 1;
-    {
-        constexpr int ch = 0;
-        const int q = tid;
-        ScatterIn in;
-        in.active = false;
-        if (q < it.z) particle_phase1<DO_G2P, DO_P2G>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
-        if (!DO_P2G) return;
-        PX_MPM_STAMP(2);
+    const int q = tid;
+    ScatterIn in;
+    in.active = false;
+    if (q < it.z) particle_phase1<DO_G2P, DO_P2G, SCHED>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
+    if (!DO_P2G) return;
+    PX_MPM_STAMP(2);
 
-        // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----
-        Stencil st;
-        int b0 = -1;
-        if (in.active) {
-            st = make_stencil(in.x[0], in.x[1], in.x[2], S.inv_dx);
-            if (!stencil_inside(st, ng)) {
-                atomicAdd(S.oob, 1ull);
-                S.selection[it.y + q] = 2;
-                in.active = false;
+    // ---- P2G: a particle whose stencil left the tile goes straight to HBM (fp32 atomics into gin) ----
+    Stencil st;
+    int b0 = -1;
+    if (in.active) {
+        st = make_stencil(in.x[0], in.x[1], in.x[2], S.inv_dx);
+        if (!stencil_inside(st, ng)) {
+            atomicAdd(S.oob, 1ull);
+            S.selection[it.y + q] = 2;
+            in.active = false;
+        } else {
+            const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
+            if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
+                b0 = (lx * kTS + ly) * kTS + lz;
             } else {
-                const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
-                if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
-                    b0 = (lx * kTS + ly) * kTS + lz;
-                } else {
-                    atomicAdd(S.oob + 1, 1ull);
-                    float mvAT[21];
+                atomicAdd(S.oob + 1, 1ull);
+                float mvAT[21];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
+                for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) { mvAT[3 + k] = in.A.m[k]; mvAT[12 + k] = in.T.m[k]; }
-                    if (!p2g_scatter_global(S.gin, S.blk_flags, S.nbk, ng, st, mvAT, in.mass)) atomicAdd(S.oob + 2, 1ull);
-                    in.active = false;
-                }
+                for (int k = 0; k < 9; ++k) { mvAT[3 + k] = in.A.m[k]; mvAT[12 + k] = in.T.m[k]; }
+                if (!p2g_scatter_global(S.gin, S.blk_flags, S.nbk, ng, st, mvAT, in.mass, TAIL ? it.x : -1)) atomicAdd(S.oob + 2, 1ull);
+                in.active = false;
             }
         }
-        // ---- workgroup bounds -> power-of-two scales ----
-        float bp = 0.0f, bm = 0.0f;
-        if (sp.trace & 0x200) { bp = 1.0f; bm = 1e-3f; }
-        else {
+    }
+    // ---- workgroup bounds -> power-of-two scales ----
+    float bp = 0.0f, bm = 0.0f;
+    if (TRACE && (sp.trace & 0x200)) { bp = 1.0f; bm = 1e-3f; }
+    else {
         if (in.active) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -588,59 +670,91 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             }
             bm = in.mass;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            bp = fmaxf(bp, __shfl_xor(bp, off, 64));
-            bm = fmaxf(bm, __shfl_xor(bm, off, 64));
-        }
+        bp = wave_max_nonneg(bp); bm = wave_max_nonneg(bm);
         if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
         __syncthreads();
         bp = s_red[0][0]; bm = s_red[1][0];
         for (int w = 1; w < (nthr >> 6); ++w) { bp = fmaxf(bp, s_red[0][w]); bm = fmaxf(bm, s_red[1][w]); }
-        }
-        const float sP = scale_for(bp), sM = scale_for(bm);
-        PX_MPM_STAMP(3);
+    }
+    constexpr int kTop = PACK ? 21 : 41;
+    const float sP = scale_for(bp, kTop), sM = scale_for(bm, kTop);
+    PX_MPM_STAMP(3);
 
-        if (in.active) {
+    if (in.active) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
+        for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { in.A.m[k] *= sP; in.T.m[k] *= sP; }
-            p2g_scatter(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
-                const int idx = b0 + (i * kTS + j) * kTS + k;
-                if (sp.trace & 0x100) { asm volatile("" :: "v"(mom[0]), "v"(mom[1]), "v"(mom[2]), "v"(m)); return; }
+        for (int k = 0; k < 9; ++k) { in.A.m[k] *= sP; in.T.m[k] *= sP; }
+        p2g_scatter<SCHED>(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
+            const int idx = b0 + (i * kTS + j) * kTS + k;
+            if (TRACE && (sp.trace & 0x100)) { asm volatile("" :: "v"(mom[0]), "v"(mom[1]), "v"(mom[2]), "v"(m)); return; }
+            if (PACK) {
+                atomicAdd(&ta[0][idx], pack_pair(round_to_int(mom[0]), round_to_int(mom[1])));
+                // the mass is never negative: in the low half it needs no borrow correction
+                atomicAdd(&ta[1][idx], (unsigned long long)(unsigned)round_to_int(m) | ((unsigned long long)(unsigned)round_to_int(mom[2]) << 32));
+            } else {
                 atomicAdd(&ta[0][idx], to_fixed(mom[0]));
                 atomicAdd(&ta[1][idx], to_fixed(mom[1]));
                 atomicAdd(&ta[2][idx], to_fixed(mom[2]));
                 atomicAdd(&ta[3][idx], to_fixed(m));
-            });
-        }
-        __syncthreads();
-        PX_MPM_STAMP(4);
-        const float iP = 1.0f / sP, iM = 1.0f / sM;
-        if (nchunks == 1) {
-            // ---- publish the tile: plain coalesced stores; the grid kernel sums the tiles that cover each node ----
-            float4* dst = S.part + (size_t)blockIdx.x * kTN;
-            if (!(sp.trace & 0x800))
-            for (int idx = tid; idx < kTN; idx += nthr)
-                dst[staged_index(idx >> 6, (idx >> 3) & 7, idx & 7)] = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
-                                       from_fixed(ta[3][idx], iM));
-        } else {
-            for (int idx = tid; idx < kTN; idx += nthr) {
-                float4 v = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP),
-                                       from_fixed(ta[3][idx], iM));
-                if (ch > 0) { const float4 o = tf[idx]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                if (ch == nchunks - 1) S.part[(size_t)blockIdx.x * kTN + staged_index(idx >> 6, (idx >> 3) & 7, idx & 7)] = v;
-                else { tf[idx] = v; ta[0][idx] = 0ull; ta[1][idx] = 0ull; ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
             }
-            __syncthreads();
+        });
+    }
+    __syncthreads();
+    PX_MPM_STAMP(4);
+    const float iP = 1.0f / sP, iM = 1.0f / sM;
+    // ---- publish the tile: coalesced stores; the grid update sums the tiles that cover each node ----
+    float4* dst = S.part + (size_t)blockIdx.x * kTN;
+    if (!(TRACE && (sp.trace & 0x800)))
+        for (int idx = tid; idx < kTN; idx += nthr) {
+            float4 o;
+            if (PACK) {
+                int px, py, pm, pz;
+                unpack_pair(ta[0][idx], px, py);
+                const unsigned long long w1 = ta[1][idx];
+                pm = (int)(unsigned)w1; pz = (int)(unsigned)(w1 >> 32);
+                o = make_float4((float)px * iP, (float)py * iP, (float)pz * iP, (float)pm * iM);
+            } else {
+                o = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP), from_fixed(ta[3][idx], iM));
+            }
+            float4* d = dst + staged_index(idx >> 6, (idx >> 3) & 7, idx & 7);
+            if (TAIL) store_through(d, o);
+            else *d = o;
         }
-        PX_MPM_STAMP(5);
-        if (DO_G2P && DO_P2G && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
-            g_mpm_trace[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+    PX_MPM_STAMP(5);
+    if (TRACE && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
+        g_mpm_trace[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+
+    if (TAIL) {
+        // ---- grid update in the tail.  A node block (4x4x4 nodes) is complete when every work item of its 27 neighbour
+        // blocks has published its tile; the item that makes the count reach `expected` updates that block (normalise,
+        // gravity, damping, BCs -> gout_next).  Nobody ever waits: the protocol is a last-arriver reduction (as in a split-K
+        // epilogue), so it cannot deadlock whatever the dispatch order.  Visibility: tiles are stored write-through
+        // (sc0 sc1) and each wave drains its vmcnt before it counts itself in; the wave that finds the other waves of its
+        // work item already counted raises the device-scope counters; the gather reads with sc0 sc1 loads.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int lane = tid & 63;
+        int prev = 0;
+        if (lane == 0) prev = atomicAdd(&s_done, 1);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev != (nthr >> 6) - 1) return;
+        const int my_slot = S.blk_slot[it.x];
+        int nslot = -1, old = -2, want = -1;
+        if (lane < 27) nslot = S.nbr_slots[(size_t)my_slot * 27 + lane];
+        if (nslot >= 0) {
+            want = S.expected[nslot];
+            old = __hip_atomic_fetch_add(&S.arrive[nslot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long todo = __ballot(nslot >= 0 && old + 1 == want);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int slot = __shfl(nslot, src);
+            if (lane == 0) S.arrive[slot] = 0;    // nobody touches it again before the next launch
+            grid_block_update<1, true>(S, sp, bcs, slot, S.gout_next);
+        }
     }
 }
-
 // ------------------------------------------------------------------ re-binning (counting sort by block)
 __device__ __forceinline__ int block_of(const MpmPtrs& S, int p) {
     int b[3];
@@ -767,7 +881,8 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
 // ones the grid kernel is launched for (workgroup dispatch alone costs ~10 us for the 27000 blocks of a 120^3 grid).
 __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restrict__ counts, int* __restrict__ blk_flags,
                                                               int* __restrict__ active_list, int* __restrict__ n_active, int nbk,
-                                                              const int2* __restrict__ blk_items, int2* __restrict__ nbr_table) {
+                                                              const int2* __restrict__ blk_items, int2* __restrict__ nbr_table,
+                                                              int* __restrict__ blk_slot) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbk * nbk * nbk) return;
     const int bz = b % nbk, by = (b / nbk) % nbk, bx = b / (nbk * nbk);
@@ -780,9 +895,10 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
                     active = active || counts[(x * nbk + y) * nbk + z] > 0;
             }
     blk_flags[b] = active ? 1 : 0;
-    if (!active) return;
+    if (!active) { blk_slot[b] = -1; return; }
     const int slot = atomicAdd(n_active, 1);
     active_list[slot] = b;
+    blk_slot[b] = slot;
     // everything the grid kernel needs to find this block's tiles, in one 224-byte row: one memory round trip there
     // instead of active_list -> blk_items -> tiles
     int2* row = nbr_table + (size_t)slot * 28;
@@ -792,6 +908,26 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
         const bool in = (unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk;
         row[1 + q] = in ? blk_items[(x * nbk + y) * nbk + z] : make_int2(0, 0);
     }
+}
+
+// Tables of the tail grid update (grid_tail in the block kernel): for every active block the slots of its 27 neighbours,
+// the number of work items whose tiles cover it (= arrivals that complete it), and a cleared arrival counter.
+__global__ __launch_bounds__(256) void bin_tail_tables_kernel(const int* __restrict__ active_list, const int* __restrict__ n_active, int nbk,
+                                                              const int* __restrict__ blk_slot, const int2* __restrict__ nbr_table,
+                                                              int* __restrict__ nbr_slots, int* __restrict__ expected, int* __restrict__ arrive) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= *n_active) return;
+    const int b = active_list[slot];
+    const int bz = b % nbk, by = (b / nbk) % nbk, bx = b / (nbk * nbk);
+    int total = 0;
+    for (int q = 0; q < 27; ++q) {
+        const int x = bx + q / 9 - 1, y = by + (q / 3) % 3 - 1, z = bz + q % 3 - 1;
+        const bool in = (unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk;
+        nbr_slots[(size_t)slot * 27 + q] = in ? blk_slot[(x * nbk + y) * nbk + z] : -1;
+        total += nbr_table[(size_t)slot * 28 + 1 + q].y;
+    }
+    expected[slot] = total;
+    arrive[slot] = 0;
 }
 
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
@@ -874,9 +1010,12 @@ __device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By
     }
     return mine;
 }
+// RB = items per candidate block fetched in one go (8 x RB tile loads in flight); SC = read with sc0 sc1 (device-coherent)
+// buffer loads: the tail of the block kernel gathers tiles other workgroups published in the SAME launch.
+template <int RB, bool SC>
 __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
     const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
-    const float4* ptr[8];
+    unsigned off[8];   // in float4 units from S.part
     int cnt[8];
     int maxc = 0;
 #pragma unroll
@@ -885,59 +1024,41 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
         const int src = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
         const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
         const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;  // this node inside that block's tile
-        ptr[c] = S.part + (size_t)first * kTN + staged_index(tx, ty, tz);
+        off[c] = (unsigned)first * kTN + (unsigned)staged_index(tx, ty, tz);
         cnt[c] = n;
         maxc = max(maxc, n);
     }
-    // up to 4 items per block in one go: all 32 tile loads of a node are issued before the first is consumed
-    for (int r0 = 0; r0 < maxc; r0 += 4) {
-        float4 q[4][8];
+    __amdgpu_buffer_rsrc_t rs;
+    if (SC) rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.part, 0, 0x7fffffff, 0x00020000);   // raw buffer, 32-bit byte offsets (host checks the size)
+    // up to RB items per block in one go: all 8 x RB tile loads of a node are issued before the first is consumed
+    for (int r0 = 0; r0 < maxc; r0 += RB) {
+        float4 q[RB][8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                q[r][c] = (r0 + r < cnt[c]) ? ptr[c][(size_t)(r0 + r) * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < 8; ++c) {
+                const bool on = r0 + r < cnt[c];
+                const unsigned o = off[c] + (unsigned)(r0 + r) * kTN;
+                if (SC) {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rs, on ? (int)(o * 16u) : 0, 0, 0x11);   // aux: sc0 | sc1
+                    q[r][c] = on ? make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w))
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    q[r][c] = on ? S.part[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
     }
     return acc;
 }
 
-// One wave per 4x4x4 block of nodes: gather (above), grid_normalization_and_gravity, damping, BCs.
-// A block is ACTIVE when one of its 27 neighbours (itself included) holds particles, or a slow-path particle wrote
-// into it (blk_flags).  Only active blocks are read by the next G2P (a tile reaches one block beyond its own), so
-// inactive blocks are skipped entirely (mode 0); their grid_v_out is brought up to date on demand (mode 1, used by
-// the grid_v_out export) with the parameters of the last update, which for a massless node is just the BCs on v = 0.
-__global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
-    int blk = (int)blockIdx.x;
-    int2 mine = make_int2(0, 0);
-    if (mode == 0) {   // one coalesced row: block id + the work items of the 27 neighbours (lane q holds neighbour q)
-        const int lane = threadIdx.x;
-        const int2 row = (lane < 28) ? S.nbr_table[(size_t)blockIdx.x * 28 + lane] : make_int2(0, 0);
-        blk = __shfl(row.x, 0);
-        mine.x = __shfl(row.x, (lane + 1) & 63); mine.y = __shfl(row.y, (lane + 1) & 63);
-    }
-    const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
-    const int flag = S.blk_flags[blk];  // bit 0: active (set at re-binning); bit 1: slow-path writes
-    if (mode == 1) {
-        if (flag & 1) return;
-        mine = neighbour_items(S, Bx, By, Bz);
-    }
-    const int lx = threadIdx.x >> 4, ly = (threadIdx.x >> 2) & 3, lz = threadIdx.x & 3;
-    const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
-    const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
-    const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mode == 0) {
-        g = gather_node(S, mine, lx, ly, lz, g);   // does not wait for the flag
-        if (flag & 2) {  // slow-path particles added fp32 atomics into gin here
-            if (inside) { const float4 q = S.gin[idx]; g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w; S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
-            if (threadIdx.x == 0) S.blk_flags[blk] = flag & 1;
-        }
-    }
-    if (!inside) return;
+// grid_normalization_and_gravity (mpm_utils.py:398-409), add_damping_via_grid (:583-588) and every BC for ONE node of block
+// (Bx,By,Bz), from its accumulated (m*v, m); returns grid_v_out
+__device__ __forceinline__ float4 finish_node(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, float4 g, int ix, int iy, int iz) {
     float v[3] = {0.0f, 0.0f, 0.0f};
     if (g.w > 1e-15f) {
         const float inv = 1.0f / g.w;
@@ -947,7 +1068,65 @@ __global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParam
     }
     if (sp.do_damping) { v[0] *= sp.damping; v[1] *= sp.damping; v[2] *= sp.damping; }
     for (int k = 0; k < bcs.n; ++k) apply_bc(bcs.bc[k], ix, iy, iz, S.ng, S.dx, sp.time, sp.dt, v);
-    S.gout[idx] = make_float4(v[0], v[1], v[2], 0.0f);
+    return make_float4(v[0], v[1], v[2], 0.0f);
+}
+
+// One WAVE updates the 4x4x4 nodes of active block `slot`: gather the staged tiles (+ what slow-path particles added to gin),
+// normalise, gravity, damping, BCs -> dst.  Called by mpm_grid_block_kernel (one wave per block, after the block kernel) and,
+// with SC, from the tail of the block kernel by the work item that completed the block.
+template <int RB, bool SC>
+__device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, int slot, float4* dst) {
+    const int lane = threadIdx.x & 63;
+    // one coalesced row: block id + the work items of the 27 neighbours (lane q holds neighbour q)
+    const int2 row = (lane < 28) ? S.nbr_table[(size_t)slot * 28 + lane] : make_int2(0, 0);
+    const int blk = __shfl(row.x, 0);
+    int2 mine;
+    mine.x = __shfl(row.x, (lane + 1) & 63); mine.y = __shfl(row.y, (lane + 1) & 63);
+    const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
+    // bit 0: active (set at re-binning); bit 1: slow-path particles added fp32 atomics into gin here
+    const int flag = SC ? __hip_atomic_load(&S.blk_flags[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.blk_flags[blk];
+    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
+    const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
+    const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
+    const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
+    float4 g = gather_node<RB, SC>(S, mine, lx, ly, lz, make_float4(0.f, 0.f, 0.f, 0.f));   // does not wait for the flag
+    if (flag & 2) {
+        if (inside) {
+            float4 q;
+            if (SC) {   // the atomics went to memory behind the L2s; read them there
+                float* cell = reinterpret_cast<float*>(S.gin + idx);
+                q.x = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.y = __hip_atomic_load(cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.z = __hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.w = __hip_atomic_load(cell + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                q = S.gin[idx];
+            }
+            g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
+            S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        if (lane == 0) S.blk_flags[blk] = flag & 1;
+    }
+    if (!inside) return;
+    dst[idx] = finish_node(S, sp, bcs, g, ix, iy, iz);
+}
+
+// One wave per 4x4x4 block of nodes.  A block is ACTIVE when one of its 27 neighbours (itself included) holds particles.
+// Only active blocks are read by the next G2P (a tile reaches one block beyond its own), so inactive blocks are skipped
+// entirely (mode 0); their grid_v_out is brought up to date on demand (mode 1, used by the grid_v_out export) with the
+// parameters of the last update, which for a massless node is just the BCs on v = 0.
+__global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
+    if (mode == 0) {
+        grid_block_update<4, false>(S, sp, bcs, (int)blockIdx.x, S.gout);
+        return;
+    }
+    const int blk = (int)blockIdx.x;
+    if (S.blk_flags[blk] & 1) return;
+    const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
+    const int lx = threadIdx.x >> 4, ly = (threadIdx.x >> 2) & 3, lz = threadIdx.x & 3;
+    const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
+    if (!(ix < S.ng && iy < S.ng && iz < S.ng)) return;
+    S.gout[((size_t)ix * S.ng + iy) * S.ng + iz] = finish_node(S, sp, bcs, make_float4(0.f, 0.f, 0.f, 0.f), ix, iy, iz);
 }
 
 // export of grid_m / grid_v_in while a P2G is pending (tiles not yet consumed by the grid kernel)
@@ -959,7 +1138,7 @@ __global__ __launch_bounds__(64) void grid_export_pending_kernel(MpmPtrs S, floa
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) g = S.gin[idx];
-    g = gather_node(S, neighbour_items(S, Bx, By, Bz), lx, ly, lz, g);
+    g = gather_node<4, false>(S, neighbour_items(S, Bx, By, Bz), lx, ly, lz, g);
     if (!inside) return;
     if (what == 0) out[idx] = g.w;
     else { out[3 * idx] = g.x; out[3 * idx + 1] = g.y; out[3 * idx + 2] = g.z; }
@@ -1014,6 +1193,12 @@ __global__ void soa_to_aos_kernel(const T* __restrict__ src, T* __restrict__ dst
     if (i >= n) return;
     const int s = perm ? perm[i] : i;
     for (int c = 0; c < k; ++c) dst[(size_t)s * k + c] = src[(size_t)c * n + i];
+}
+// selection 2 = "left the grid, frozen" (our marker; the reference has no such state): cleared when the caller replaces the
+// positions or re-makes the grid, so that particles that are inside again take part again
+__global__ void unfreeze_kernel(int* selection, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && selection[i] == 2) selection[i] = 0;
 }
 template <typename T>
 __global__ void fill_kernel(T* dst, long count, T value) {
@@ -1190,6 +1375,15 @@ struct pixie_mpm {
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
     int2* nbr_table = nullptr;               // 28 int2 per active block (see MpmPtrs)
+    int *arrive = nullptr, *expected = nullptr, *blk_slot = nullptr, *nbr_slots = nullptr;   // tail grid update (MpmPtrs)
+    float4* gout2 = nullptr;                 // ping-pong partner of S.gout
+    int fuse_grid = 1;                       // grid update in the tail of the block kernel: one launch per substep (set_scalar "fuse_grid")
+    bool tail_ok = true;                     // the staged tiles fit the 31-bit offsets of the tail's buffer loads
+    int scatter_bits = 64;                   // 64: exact fixed point (4 LDS atomics per node); 32: packed pairs (2 per node)
+    int wide = -1;                           // -1 auto: the latency-optimised variant when the scene cannot fill the chip; 0/1 forced
+    int n_cus = 256;
+    bool grid_in_tail = false;               // the last P2G launch also did its grid update (launch_grid then only advances the BCs)
+    bool profile_split = false;              // set_scalar "profile" 2: time block and grid kernels separately (no tail fusion)
     int n_active = 0;
     bool gout_sparse = false;                // inactive blocks of gout are stale (refreshed on export)
     StepParams last_grid_sp{};
@@ -1209,8 +1403,8 @@ template <typename T>
 int dev_alloc(pixie_mpm* h, T** ptr, size_t count, bool grid_sized = false) {
     void* p = nullptr;
     PX_CHECK_HIP(hipMalloc(&p, count * sizeof(T)));
-    PX_CHECK_HIP(hipMemset(p, 0, count * sizeof(T)));
     (grid_sized ? h->grid_allocs : h->allocs).push_back(p);
+    PX_CHECK_HIP(hipMemset(p, 0, count * sizeof(T)));
     *ptr = static_cast<T*>(p);
     return 0;
 }
@@ -1226,6 +1420,7 @@ void bind_rows(pixie_mpm* h) {
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
     S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n;
     S.items = h->items; S.part = h->part; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
+    S.arrive = h->arrive; S.expected = h->expected; S.blk_slot = h->blk_slot; S.nbr_slots = h->nbr_slots;
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -1244,7 +1439,9 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, h->item_cap);
     PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 1, 0, sizeof(int), st));
     hipLaunchKernelGGL(bin_mark_active_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->counts, h->blk_flags, h->active_list,
-                       h->d_n_items + 1, S.nbk, h->blk_items, h->nbr_table);  // (rewrites every flag: no slow-path writes are pending here)
+                       h->d_n_items + 1, S.nbk, h->blk_items, h->nbr_table, h->blk_slot);  // (rewrites every flag: no slow-path writes are pending here)
+    hipLaunchKernelGGL(bin_tail_tables_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->active_list, h->d_n_items + 1, S.nbk,
+                       h->blk_slot, h->nbr_table, h->nbr_slots, h->expected, h->arrive);
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
     // keys/rank are free again: reuse them as the local kernel's scratch
     hipLaunchKernelGGL(bin_local_order_kernel, dim3((unsigned)h->nblocks), dim3(256), 0, st, S, h->counts, h->offsets, h->order, h->keys,
@@ -1336,7 +1533,51 @@ bool find_field(pixie_mpm* h, const std::string& name, FieldInfo* fi) {
     return false;
 }
 
-int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st) {
+// The BCs of one launch, as the kernels take them
+BCSet make_bcset(const pixie_mpm* h, size_t first) {
+    BCSet set{};
+    set.n = (int)std::min<size_t>(kMaxBCPerLaunch, h->bcs_dev.size() - std::min(first, h->bcs_dev.size()));
+    for (int k = 0; k < set.n; ++k) set.bc[k] = h->bcs_dev[first + k];
+    return set;
+}
+
+// host `modify` of moving cuboids (mpm_solver_warp.py:899-905) after the grid update of the substep at h->time:
+// python-float maths, stored as f32
+void advance_bcs(pixie_mpm* h, double dt) {
+    for (size_t k = 0; k < h->bcs.size(); ++k) {
+        pixie_bc_desc& b = h->bcs[k];
+        if (b.type != PIXIE_BC_CUBOID) continue;
+        const double t0 = (double)(float)b.start_time, t1 = (double)(float)b.end_time;
+        if (h->time >= t0 && h->time < t1) {
+            for (int d = 0; d < 3; ++d) {
+                const float np = (float)((double)h->bcs_dev[k].point[d] + dt * (double)h->bcs_dev[k].velocity[d]);
+                h->bcs_dev[k].point[d] = np;
+                b.point[d] = np;
+            }
+        }
+    }
+}
+
+// the grid update can ride in the tail of a P2G launch when one launch carries every BC and the tiles are addressable
+bool tail_possible(const pixie_mpm* h) {
+    return h->fuse_grid && h->tail_ok && h->bcs_dev.size() <= (size_t)kMaxBCPerLaunch && !h->profile_split;
+}
+
+template <bool G, bool P, int OCC, int FL>
+void launch_block(const pixie_mpm* h, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms, const BCSet& bcs) {
+    hipLaunchKernelGGL((mpm_block_kernel<G, P, OCC, FL>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms, bcs);
+}
+// FL without F_WIDE / F_TRACE: the four (packed, tail) combinations
+template <bool G, bool P, int OCC, int BASE>
+void launch_block_pt(const pixie_mpm* h, bool pack, bool tail, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms, const BCSet& bcs) {
+    if (pack && tail) launch_block<G, P, OCC, BASE | F_PACK32 | F_TAIL>(h, grid, st, sp, pms, bcs);
+    else if (pack) launch_block<G, P, OCC, BASE | F_PACK32>(h, grid, st, sp, pms, bcs);
+    else if (tail) launch_block<G, P, OCC, BASE | F_TAIL>(h, grid, st, sp, pms, bcs);
+    else launch_block<G, P, OCC, BASE>(h, grid, st, sp, pms, bcs);
+}
+
+// `tail`: do the grid update of this P2G in the same launch (the caller checked tail_possible)
+int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st, bool tail = false) {
     // (never while staged tiles are waiting for the grid kernel: the work list they are indexed by must not change)
     if (!h->pending_p2g && (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval)))
         if (rebin(h, st)) return 1;
@@ -1360,25 +1601,37 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         for (int k = 0; k < pms.n; ++k) pms.pm[k] = ordered[k];
     }
     if (h->n_items == 0) return 0;  // no particles binned (n_particles > 0 always gives >= 1 item)
+    tail = tail && p2g;
+    const BCSet bcs = tail ? make_bcset(h, 0) : BCSet{};
+    const bool pack = h->scatter_bits == 32;
+    // Latency-optimised variant (no scheduling barriers, register budget of 2 waves per SIMD): when the whole work list is
+    // resident at once with room to spare (<= 2 work items per CU) nothing is gained from occupancy and the launch lasts
+    // one work item's latency.
+    const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 2 * h->n_cus);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile && p2g && g2p) {
         PX_CHECK_HIP(hipEventCreate(&e0)); PX_CHECK_HIP(hipEventCreate(&e1));
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        if (h->occupancy >= 6) hipLaunchKernelGGL((mpm_block_kernel<true, true, 6>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
-        else hipLaunchKernelGGL((mpm_block_kernel<true, true, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+        if (h->trace) {
+            if (pack) launch_block<true, true, 5, F_TRACE | F_PACK32>(h, grid, st, sp, pms, bcs);
+            else launch_block<true, true, 5, F_TRACE>(h, grid, st, sp, pms, bcs);
+            tail = false;
+        } else if (wide) launch_block_pt<true, true, 2, F_WIDE>(h, pack, tail, grid, st, sp, pms, bcs);
+        else if (h->occupancy >= 6 && !pack && !tail) launch_block<true, true, 6, 0>(h, grid, st, sp, pms, bcs);
+        else launch_block_pt<true, true, 5, 0>(h, pack, tail, grid, st, sp, pms, bcs);
     } else {
         if (g2p) {
             PModSet none{};
-            hipLaunchKernelGGL((mpm_block_kernel<true, false, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, none);
+            launch_block<true, false, 5, 0>(h, grid, st, sp, none, BCSet{});
         }
         if (p2g) {
             if (!fused_mods) {
                 for (const PModDev& m : ordered)
                     hipLaunchKernelGGL(pmod_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, m);
             }
-            hipLaunchKernelGGL((mpm_block_kernel<false, true, 5>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
+            launch_block_pt<false, true, 5, 0>(h, pack, tail, grid, st, sp, pms, bcs);
         }
     }
     if (e0) {
@@ -1386,11 +1639,25 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         h->ev_particle.emplace_back(e0, e1);
     }
     PX_CHECK_HIP(hipGetLastError());
-    if (p2g) h->pending_p2g = true;
+    if (p2g && !tail) h->pending_p2g = true;
+    if (p2g && tail) {   // the launch wrote the new grid velocities into the partner array
+        std::swap(h->S.gout, h->S.gout_next);
+        h->gout_sparse = true;
+        h->last_grid_sp = sp;
+        h->last_grid_bcs.assign(h->bcs_dev.begin(), h->bcs_dev.end());
+        h->grid_in_tail = true;
+    } else if (p2g) {
+        h->grid_in_tail = false;
+    }
     return 0;
 }
 
 int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
+    if (h->grid_in_tail) {   // already done by the P2G launch
+        h->grid_in_tail = false;
+        advance_bcs(h, dt);
+        return 0;
+    }
     const long total = (long)h->S.ng * h->S.ng * h->S.ng;
     const int blocks = cdiv(total, 256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1402,9 +1669,7 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
     size_t done = 0;
     int normalise = 1;
     do {
-        BCSet set{};
-        set.n = (int)std::min<size_t>(kMaxBCPerLaunch, nbc - done);
-        for (int k = 0; k < set.n; ++k) set.bc[k] = h->bcs_dev[done + k];
+        const BCSet set = make_bcset(h, done);
         if (normalise && h->pending_p2g && nbc <= (size_t)kMaxBCPerLaunch) {
             // staged tiles of the last P2G + slow-path atomics in gin; blocks with nothing nearby are skipped
             hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)std::max(h->n_active, 1)), dim3(64), 0, st, h->S, sp, set, 0);
@@ -1428,48 +1693,57 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
         h->ev_grid.emplace_back(e0, e1);
     }
     PX_CHECK_HIP(hipGetLastError());
-    // host `modify` of moving cuboids (mpm_solver_warp.py:899-905): python-float maths, stored as f32
-    for (size_t k = 0; k < nbc; ++k) {
-        pixie_bc_desc& b = h->bcs[k];
-        if (b.type != PIXIE_BC_CUBOID) continue;
-        const double t0 = (double)(float)b.start_time, t1 = (double)(float)b.end_time;
-        if (h->time >= t0 && h->time < t1) {
-            for (int d = 0; d < 3; ++d) {
-                const float np = (float)((double)h->bcs_dev[k].point[d] + dt * (double)h->bcs_dev[k].velocity[d]);
-                h->bcs_dev[k].point[d] = np;
-                b.point[d] = np;
-            }
-        }
-    }
+    advance_bcs(h, dt);
     return 0;
 }
 
-// Everything whose size depends on n_grid: the two grid arrays, the block tables and the work list / staged tiles.
+// Everything whose size depends on n_grid: the grid arrays, the block tables and the work list / staged tiles.
 // Used by pixie_mpm_create and by pixie_mpm_regrid (set_parameters_dict changing n_grid / grid_lim after the particles
 // were loaded, mpm_solver_warp.py:315-342: the reference re-allocates the grids and recomputes dx, nothing else).
+// The new buffers are allocated first; the old ones are released only when every allocation succeeded, so a failed
+// regrid leaves the handle as it was.
 int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     MpmPtrs& S = h->S;
-    for (void* p : h->grid_allocs) (void)hipFree(p);
-    h->grid_allocs.clear();
+    const int nbk = (n_grid + kBS - 1) / kBS;
+    const int nblocks = nbk * nbk * nbk;
+    const size_t n = (size_t)S.n, G = (size_t)n_grid * n_grid * n_grid;
+    const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)nblocks, n);   // for the smallest capacity (64)
+    std::vector<void*> old;
+    old.swap(h->grid_allocs);
+    float4 *gin = nullptr, *gout = nullptr, *gout2 = nullptr, *part = nullptr;
+    int *counts = nullptr, *offsets = nullptr, *active_list = nullptr, *blk_flags = nullptr, *arrive = nullptr, *expected = nullptr, *blk_slot = nullptr, *nbr_slots = nullptr;
+    int4* items = nullptr;
+    int2 *nbr_table = nullptr, *blk_items = nullptr;
+    int rc = 0;
+    rc |= dev_alloc(h, &gin, G, true); rc |= dev_alloc(h, &gout, G, true); rc |= dev_alloc(h, &gout2, G, true);
+    rc |= dev_alloc(h, &counts, (size_t)nblocks, true); rc |= dev_alloc(h, &offsets, (size_t)nblocks, true);
+    rc |= dev_alloc(h, &items, max_items, true);
+    rc |= dev_alloc(h, &active_list, (size_t)nblocks, true);
+    rc |= dev_alloc(h, &nbr_table, (size_t)nblocks * 28, true);
+    rc |= dev_alloc(h, &blk_items, (size_t)nblocks, true); rc |= dev_alloc(h, &blk_flags, (size_t)nblocks, true);
+    rc |= dev_alloc(h, &part, max_items * kTN, true);
+    rc |= dev_alloc(h, &arrive, (size_t)nblocks, true); rc |= dev_alloc(h, &expected, (size_t)nblocks, true);
+    rc |= dev_alloc(h, &blk_slot, (size_t)nblocks, true); rc |= dev_alloc(h, &nbr_slots, (size_t)nblocks * 27, true);
+    if (rc) {   // keep the old grid
+        for (void* p : h->grid_allocs) (void)hipFree(p);
+        h->grid_allocs.swap(old);
+        return 1;
+    }
+    for (void* p : old) (void)hipFree(p);
     S.ng = n_grid;
     h->grid_lim = grid_lim;
     S.dx = (float)(grid_lim / n_grid);              // mpm_solver_warp.py:62-66, :320-326
     S.inv_dx = (float)((double)n_grid / grid_lim);
-    S.nbk = (n_grid + kBS - 1) / kBS;
-    h->nblocks = S.nbk * S.nbk * S.nbk;
-    const size_t n = (size_t)S.n, G = (size_t)n_grid * n_grid * n_grid;
-    const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)h->nblocks, n);   // for the smallest capacity (64)
-    int rc = 0;
-    rc |= dev_alloc(h, &S.gin, G, true); rc |= dev_alloc(h, &S.gout, G, true);
-    rc |= dev_alloc(h, &h->counts, (size_t)h->nblocks, true); rc |= dev_alloc(h, &h->offsets, (size_t)h->nblocks, true);
-    rc |= dev_alloc(h, &h->items, max_items, true);
-    rc |= dev_alloc(h, &h->active_list, (size_t)h->nblocks, true);
-    rc |= dev_alloc(h, &h->nbr_table, (size_t)h->nblocks * 28, true);
-    rc |= dev_alloc(h, &h->blk_items, (size_t)h->nblocks, true); rc |= dev_alloc(h, &h->blk_flags, (size_t)h->nblocks, true);
-    rc |= dev_alloc(h, &h->part, max_items * kTN, true);
+    S.nbk = nbk;
+    h->nblocks = nblocks;
+    S.gin = gin; S.gout = gout; S.gout_next = gout2; h->gout2 = gout2;
+    h->counts = counts; h->offsets = offsets; h->items = items; h->active_list = active_list; h->nbr_table = nbr_table;
+    h->blk_items = blk_items; h->blk_flags = blk_flags; h->part = part;
+    h->arrive = arrive; h->expected = expected; h->blk_slot = blk_slot; h->nbr_slots = nbr_slots;
+    h->tail_ok = max_items * kTN * sizeof(float4) < ((size_t)1 << 31);   // byte offsets of the tail's buffer loads
     h->n_items = 0; h->n_active = 0;
     h->needs_sort = true; h->xref_valid = false;
-    h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false;
+    h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false; h->grid_in_tail = false;
     if (h->resort_auto) h->resort_interval = 4;
     return rc;
 }
@@ -1493,6 +1767,10 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
     if (hipHostMalloc((void**)&h->h_n_items, 12 * sizeof(int)) != hipSuccess) { pixie_mpm_destroy(h); return set_error("hipHostMalloc failed"); }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
+    }
     bind_rows(h);
     hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.perm, n_particles);
     hipLaunchKernelGGL(identity_F_kernel, dim3(cdiv(n, 256)), dim3(256), 0, 0, S.Ft, n_particles);  // :272-277
@@ -1524,6 +1802,8 @@ int pixie_mpm_regrid(pixie_mpm* h, int n_grid, double grid_lim, void* stream) {
     PX_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));   // nothing may still be reading the old grid
     if (alloc_grid(h, n_grid, grid_lim)) return 1;
     bind_rows(h);
+    hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S.selection, h->S.n);
+    PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
@@ -1540,7 +1820,10 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     FieldInfo fi;
     PX_REQUIRE(find_field(h, nm, &fi), "set_field: unknown field '%s'", name);
     PX_REQUIRE(count == (int64_t)n * fi.k, "set_field(%s): expected %lld scalars, got %lld", name, (long long)n * fi.k, (long long)count);
-    if (nm == "x") { h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval; }  // positions replaced: binning stale
+    if (nm == "x") {   // positions replaced: binning stale, frozen particles get another chance
+        h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval;
+        hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S.selection, n);
+    }
     if (fi.is_int)
         hipLaunchKernelGGL(aos_to_soa_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)d_src, (int*)fi.ptr, n, fi.k, h->S.perm);
     else
@@ -1625,7 +1908,10 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gy") h->g[1] = (float)value;
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
-    else if (k == "profile") h->profile = value != 0.0;
+    else if (k == "profile") { h->profile = value != 0.0; h->profile_split = value == 2.0; }   // 2: block and grid kernels timed apart (no tail fusion)
+    else if (k == "fuse_grid") h->fuse_grid = value != 0.0;        // grid update in the tail of the block kernel (default on)
+    else if (k == "scatter_bits") { PX_REQUIRE(value == 64 || value == 32, "scatter_bits must be 64 (exact) or 32 (packed pairs)"); h->scatter_bits = (int)value; }
+    else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
     else if (k == "trace") h->trace = (int)value;
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
@@ -1645,6 +1931,9 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "grid_v_damping_scale") *value = h->damping;
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
+    else if (k == "fuse_grid") *value = tail_possible(h) ? 1.0 : 0.0;
+    else if (k == "scatter_bits") *value = h->scatter_bits;
+    else if (k == "n_active_blocks") *value = h->n_active;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
     else if (k == "lost_particles_seen") *value = (double)h->lost_seen;   // as of the last re-binning; does not synchronise
     else if (k == "dropped_particles") {  // slow-path particles that had left every active block; synchronises the device
@@ -1722,14 +2011,17 @@ int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream) {
     if (n_substeps == 0) return 0;
     PX_REQUIRE(!h->dirty_grid, "pixie_mpm_step: a phase-API P2G is pending; finish the substep with phases 1,2 first");
     hipStream_t st = as_stream(stream);
+    // With the grid update in the tail of every P2G launch a run of n substeps is n + 1 launches: P2G(0)+grid(0),
+    // [G2P(i) + P2G(i+1) + grid(i+1)] x (n-1), G2P(n-1).  Otherwise the grid update is its own launch (2n + 1).
+    const bool tail = tail_possible(h);
     // substep 0: modifiers + stress + P2G at time t0
-    if (launch_particle(h, false, true, make_params(h, dt, h->time), st)) return 1;
+    if (launch_particle(h, false, true, make_params(h, dt, h->time), st, tail)) return 1;
     for (int i = 0; i < n_substeps; ++i) {
-        if (launch_grid(h, make_params(h, dt, h->time), dt, st)) return 1;
+        if (launch_grid(h, make_params(h, dt, h->time), dt, st)) return 1;   // (only the BC bookkeeping when the P2G launch did it)
         h->time = h->time + dt;  // mpm_solver_warp.py:637
         const bool last = (i == n_substeps - 1);
         // G2P of substep i fused with modifiers/stress/P2G of substep i+1 (evaluated at the new time)
-        if (launch_particle(h, true, !last, make_params(h, dt, h->time), st)) return 1;
+        if (launch_particle(h, true, !last, make_params(h, dt, h->time), st, tail)) return 1;
     }
     return 0;
 }

@@ -11,8 +11,11 @@ Differences a caller can observe, by design:
   * export_*_to_torch return one persistent tensor per field in the caller's particle order, refreshed in
     place by each export call, instead of live zero-copy aliases of solver memory (the solver keeps
     particles block-sorted in SoA rows); get_field() returns fresh tensors;
-  * `run(dt, n)` / `p2g2p_n` step n substeps in one call (2 launches per substep, no host sync);
-    `p2g2p(step, dt)` is `run(dt, 1)`.
+  * `run(dt, n)` / `p2g2p_n` step n substeps in one call (one launch per substep, no host sync);
+  * `p2g2p(step, dt)` only QUEUES a substep.  The queue is flushed -- as ONE `run(dt, n)` -- by the next call that
+    observes or changes the solver (any export / get_field / set_field / `.time` / BC or parameter call, `flush()`),
+    so the reference's own loop (gs_simulation.py:633-634: `for step in range(step_per_frame): p2g2p(frame, dt)`,
+    then the per-frame export) runs the fused step loop unmodified and gives bit-identical results to `run()`.
 """
 from __future__ import annotations
 
@@ -112,6 +115,8 @@ class MPM_Simulator_WARP:
         if not torch.cuda.is_available():
             raise _lib.PixieHipError("MPM_Simulator_WARP needs a HIP device; pixie_amd has no CPU fallback")
         self._release()
+        self._pending, self._pending_dt = 0, 0.0   # substeps queued by p2g2p() and their dt
+        self._lost_reported = 0
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.n_particles = int(n_particles)
@@ -136,6 +141,7 @@ class MPM_Simulator_WARP:
         })
 
     def _release(self):
+        self._pending = 0   # queued substeps of a solver that is going away are dropped
         if getattr(self, "_h", None):
             _lib.load().pixie_mpm_destroy(self._h)
             self._h = None
@@ -157,14 +163,25 @@ class MPM_Simulator_WARP:
 
     @time.setter
     def time(self, value):
+        self.flush()
         check(_lib.load().pixie_mpm_set_scalar(self._h, b"time", float(value)), "set time")
 
+    def flush(self):
+        """Enqueue the substeps queued by p2g2p() on the current stream (asynchronous, like run())."""
+        n = getattr(self, "_pending", 0)
+        if n:
+            self._pending = 0
+            check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, self._stream), "pixie_mpm_step")
+            self._warn_if_particles_lost()
+
     def _get_scalar(self, key):
+        self.flush()
         out = C.c_double(0.0)
         check(_lib.load().pixie_mpm_get_scalar(self._h, key.encode(), C.byref(out)), f"get_scalar({key})")
         return out.value
 
     def _set_scalar(self, key, value):
+        self.flush()
         check(_lib.load().pixie_mpm_set_scalar(self._h, key.encode(), float(value)), f"set_scalar({key})")
 
     def _set_model_scalar(self, attr, value):
@@ -190,6 +207,7 @@ class MPM_Simulator_WARP:
     def set_field(self, name, value):
         dtype = torch.int32 if name in _INT_FIELDS else torch.float32
         t = self._as_device_tensor(value, dtype)
+        self.flush()
         check(_lib.load().pixie_mpm_set_field(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel(), self._stream),
               f"set_field({name})")
 
@@ -208,14 +226,17 @@ class MPM_Simulator_WARP:
             out = torch.empty((g, g, g, 3), dtype=torch.float32, device=self.device)
         else:
             raise KeyError(name)
+        self.flush()
         check(_lib.load().pixie_mpm_get_field(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), self._stream),
               f"get_field({name})")
         return out
 
     def _fill(self, name, value):
+        self.flush()
         check(_lib.load().pixie_mpm_fill_field(self._h, name.encode(), float(value), self._stream), f"fill({name})")
 
     def _update_mass(self):
+        self.flush()
         check(_lib.load().pixie_mpm_update_mass(self._h, self._stream), "update_mass")
 
     # ------------------------------------------------------------------ initial data
@@ -279,6 +300,7 @@ class MPM_Simulator_WARP:
             for params in kwargs["additional_material_params"]:
                 if isinstance(params["material"], str):
                     params["material"] = get_material_name(params["material"])
+                self.flush()
                 check(lib.pixie_mpm_apply_additional_params(self._h, d3(params["point"]), d3(params["size"]),
                                                             float(params["E"]), float(params["nu"]),
                                                             float(params["density"]), int(params["material"]),
@@ -289,6 +311,7 @@ class MPM_Simulator_WARP:
         """set_parameters_dict may change n_grid / grid_lim after the particles were loaded (:315-342): like the
         reference, only the grid arrays are re-made and dx / inv_dx recomputed; particle fields, model scalars,
         boundary conditions, particle modifiers and the time survive (pixie_mpm_regrid, in place)."""
+        self.flush()
         check(_lib.load().pixie_mpm_regrid(self._h, int(n_grid), float(grid_lim), self._stream), "pixie_mpm_regrid")
         self.n_grid, self.grid_lim = int(n_grid), float(grid_lim)
 
@@ -305,10 +328,12 @@ class MPM_Simulator_WARP:
 
     def finalize_mu_lam(self, device="cuda:0"):
         """:465-471"""
+        self.flush()
         check(_lib.load().pixie_mpm_finalize_mu_lam(self._h, 0, self._stream), "finalize_mu_lam")
 
     def finalize_mu_lam_bulk(self, device="cuda:0"):
         """:505-511"""
+        self.flush()
         check(_lib.load().pixie_mpm_finalize_mu_lam(self._h, 1, self._stream), "finalize_mu_lam_bulk")
 
     def reset_densities_and_update_masses(self, all_particle_densities, device="cuda:0"):
@@ -318,18 +343,28 @@ class MPM_Simulator_WARP:
 
     # ------------------------------------------------------------------ stepping
     def p2g2p(self, step, dt, device="cuda:0"):
-        """:514-637 -- one substep; asynchronous on the current stream."""
-        check(_lib.load().pixie_mpm_step(self._h, float(dt), 1, self._stream), "pixie_mpm_step")
-        self._warn_if_particles_lost()
+        """:514-637 -- one substep.  Deferred: the substep is queued and runs, fused with its neighbours, when the
+        solver is next observed or changed (module docstring); a change of dt flushes what was queued first."""
+        dt = float(dt)
+        if self._pending and dt != self._pending_dt:
+            self.flush()
+        self._pending_dt = dt
+        self._pending += 1
 
     def run(self, dt, n_substeps):
-        """n substeps of p2g2p in one call (fused G2P->P2G launches, no host synchronisation)."""
-        check(_lib.load().pixie_mpm_step(self._h, float(dt), int(n_substeps), self._stream), "pixie_mpm_step")
-        self._warn_if_particles_lost()
+        """n substeps of p2g2p in one call (fused G2P->P2G->grid launches, no host synchronisation)."""
+        dt = float(dt)
+        if self._pending and dt != self._pending_dt:
+            self.flush()
+        self._pending_dt = dt
+        self._pending += int(n_substeps)
+        self.flush()
 
     def _warn_if_particles_lost(self):
         """Mass leaving the simulation must not be silent: the count read back at the last re-binning (no sync)."""
-        lost = int(self._get_scalar("lost_particles_seen"))
+        out = C.c_double(0.0)
+        check(_lib.load().pixie_mpm_get_scalar(self._h, b"lost_particles_seen", C.byref(out)), "get_scalar")
+        lost = int(out.value)
         if lost > getattr(self, "_lost_reported", 0):
             import warnings
             warnings.warn(f"MPM_Simulator_WARP: {lost} particle(s) left the {self.n_grid}^3 grid (or every active block) and "
@@ -340,11 +375,13 @@ class MPM_Simulator_WARP:
 
     def phase(self, phase, dt):
         """Test hook: 0 = modifiers+stress+P2G, 1 = grid update+damping+BCs, 2 = G2P."""
+        self.flush()
         check(_lib.load().pixie_mpm_phase(self._h, int(phase), float(dt), self._stream), "pixie_mpm_phase")
 
     @property
     def out_of_bounds(self):
         cnt = C.c_int64(0)
+        self.flush()
         check(_lib.load().pixie_mpm_out_of_bounds(self._h, C.byref(cnt), self._stream), "out_of_bounds")
         return cnt.value
 
@@ -354,6 +391,7 @@ class MPM_Simulator_WARP:
     def kernel_times(self):
         """(mean fused-particle-kernel ms, mean grid-kernel ms, launches) since the last call."""
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        self.flush()
         check(_lib.load().pixie_mpm_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)), "kernel_times")
         return a.value, b.value, n.value
 
@@ -403,11 +441,13 @@ class MPM_Simulator_WARP:
 
     def export_particle_R_to_torch(self, device="cuda:0"):
         out = self._export_view("R", (self.n_particles, 9))
+        self.flush()
         check(_lib.load().pixie_mpm_export_R(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_R")
         return out
 
     def export_particle_cov_to_torch(self, device="cuda:0"):
         out = self._export_view("cov", (self.n_particles * 6,))
+        self.flush()
         check(_lib.load().pixie_mpm_export_cov(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_cov")
         return out
 
@@ -423,6 +463,7 @@ class MPM_Simulator_WARP:
         mean = [float(v) for v in (original_mean_pos.detach().cpu() if torch.is_tensor(original_mean_pos) else original_mean_pos)]
         pos = torch.empty((int(gs_num), 3), dtype=torch.float32, device=self.device)
         cov = torch.empty((int(gs_num), 6), dtype=torch.float32, device=self.device) if with_cov else None
+        self.flush()
         check(_lib.load().pixie_mpm_export_frame(self._h, int(gs_num), d3([1.0, 1.0, 1.0 + float(z_shift_value)]), float(scale_origin),
                                                  d3(mean), (C.c_double * 9)(*M.reshape(-1)), C.c_void_p(pos.data_ptr()),
                                                  C.c_void_p(cov.data_ptr()) if with_cov else None, self._stream), "export_frame")
@@ -447,6 +488,7 @@ class MPM_Simulator_WARP:
         bc.start_time = float(kw.get("start_time", 0.0))
         bc.end_time = float(kw.get("end_time", 999.0))
         bc.friction = float(kw.get("friction", 0.0))
+        self.flush()
         check(_lib.load().pixie_mpm_add_bc(self._h, C.byref(bc)), "pixie_mpm_add_bc")
 
     def add_surface_collider(self, point, normal, surface="sticky", friction=0.0, start_time=0.0, end_time=999.0):
@@ -478,6 +520,7 @@ class MPM_Simulator_WARP:
                 getattr(pm, nm)[d] = float(vals[d])
         for nm in ("half_height", "radius", "rotation_scale", "translation_scale", "start_time", "end_time"):
             setattr(pm, nm, float(kw.get(nm, 0.0)))
+        self.flush()
         check(_lib.load().pixie_mpm_add_particle_modifier(self._h, C.byref(pm), self._stream), "add_particle_modifier")
 
     def add_impulse_on_particles(self, force, dt, point=[1, 1, 1], size=[1, 1, 1], num_dt=1, start_time=0.0,

@@ -172,12 +172,19 @@ def test_fast_particles_drift_controller_and_slow_path(hip_device):
 
 
 def test_single_step_api_equals_batched(hip_device):
-    """p2g2p(step, dt) called n times (3 launches each) == run(dt, n) (fused launches) up to atomics order."""
+    """One substep per pixie_mpm_step call (p2g2p + flush: P2G launch, G2P launch) == run(dt, n) (fused launches) up to
+    the instruction schedule; the reference's own loop -- p2g2p() n times, then an export -- is DEFERRED by the shim and
+    must be bit-identical to run(dt, n)."""
     sc = mpm_ball_scene(8000, seed=4, scenario="ball")
-    a, b = make_hip(sc), make_hip(sc)
+    a, b, d = make_hip(sc), make_hip(sc), make_hip(sc)
     for i in range(20):
         a.p2g2p(i, sc["dt"])
+        a.flush()
     b.run(sc["dt"], 20)
+    for i in range(20):               # gs_simulation.py:633-634, unmodified
+        d.p2g2p(i, sc["dt"])
+    assert d._pending == 20           # nothing has been enqueued yet
+    assert abs(d.time - 20 * sc["dt"]) < 1e-12 and d._pending == 0   # observing the solver flushes the queue
     # Both are deterministic (fixed-point tile sums, fixed-order grid gather), but not the same arithmetic: the fused
     # kernel keeps v, C and F_trial in registers between G2P and the next P2G, the single-step API stores and reloads
     # them through the caller-visible arrays in between (bit-identical values) and runs the stress on its own launch
@@ -189,6 +196,165 @@ def test_single_step_api_equals_batched(hip_device):
     c.run(sc["dt"], 20)
     for f in ("x", "v", "C", "F_trial"):
         assert np.array_equal(get(b, f), get(c, f)), f"run() is not bit-reproducible in {f}"
+        assert np.array_equal(get(b, f), get(d, f)), f"the deferred p2g2p loop differs from run() in {f}"
+    # a change of dt inside the loop flushes what was queued with the old one
+    e, f2 = make_hip(sc), make_hip(sc)
+    for i in range(5):
+        e.p2g2p(i, sc["dt"])
+    for i in range(5):
+        e.p2g2p(i, 0.5 * sc["dt"])
+    f2.run(sc["dt"], 5); f2.run(0.5 * sc["dt"], 5)
+    assert np.array_equal(get(e, "x"), get(f2, "x")) and abs(e.time - f2.time) < 1e-15
+
+
+@pytest.mark.parametrize("n,n_grid", [(20000, 50), (150000, 64)])
+def test_grid_update_in_kernel_tail_equals_separate_launch(hip_device, n, n_grid):
+    """Default: the grid update (normalise, gravity, damping, BCs) runs in the tail of the P2G launch, by the work item
+    that completes a node block (last-arriver reduction over tiles published write-through in the same launch).  With
+    "fuse_grid" 0 it is the separate mpm_grid_block_kernel.  Same tiles, same fixed summation order: bit-identical.
+    The small scene runs the latency-optimised kernel variant (<= 2 work items per CU), the large one the 5-waves one."""
+    sc = mpm_ball_scene(n, seed=6, n_grid=n_grid, scenario="ball")
+    res = {}
+    for fuse in (1, 0):
+        h = make_hip(sc)
+        h._set_scalar("fuse_grid", fuse)
+        h._set_scalar("wide", 0)
+        assert int(h._get_scalar("fuse_grid")) == fuse
+        h.run(sc["dt"], 150)
+        res[fuse] = {f: get(h, f) for f in ("x", "v", "C", "F_trial", "grid_v_out")}
+        assert h.out_of_bounds == 0
+    for f in res[0]:
+        assert np.array_equal(res[0][f], res[1][f]), f"{f}: tail grid update differs from the separate launch"
+    # the variant without scheduling barriers is the same arithmetic in another instruction order
+    w = make_hip(sc)
+    w._set_scalar("wide", 1)
+    w.run(sc["dt"], 150)
+    for f in ("x", "F_trial"):
+        assert rel_l2(get(w, f), res[1][f]) < 1e-6
+    assert rel_l2(get(w, "v"), res[1]["v"]) < 1e-4
+
+
+def test_tail_grid_update_with_slow_path_and_moving_bc(hip_device):
+    """The tail protocol under stress: stale binning (slow-path particles adding fp32 atomics into gin for node blocks
+    that other work items complete), a moving cuboid (host-side BC bookkeeping between launches) -- against the oracle
+    and against the separate-launch route."""
+    sc = mpm_ball_scene(20000, seed=12, scenario="ball")
+    sc["params"] = dict(material="jelly", g=[0.0, 0.0, 0.0], E=2e5, nu=0.3, density=500.0)
+    sc["bcs"] = [dict(type="cuboid", point=[1.0, 1.0, 0.6], size=[0.2, 0.2, 0.05], velocity=[0.0, 0.5, 0.0], start_time=0.0, end_time=4e-3, reset=1)]
+    v0 = np.tile(np.array([[30.0, -12.0, 7.0]], np.float32), (20000, 1))
+    o = make_oracle(sc, "f64")
+    o.field("v")[:] = v0
+    o.run(sc["dt"], 60)
+    out = {}
+    for fuse in (1, 0):
+        h = make_hip(sc)
+        h.set_field("v", v0)
+        h._set_scalar("fuse_grid", fuse)
+        h._set_scalar("resort_interval", 20)   # 1.5 cells of drift between re-binnings: past the tile's margin
+        h.run(sc["dt"], 60)
+        assert h._get_scalar("slow_path_particles") > 0 and h._get_scalar("dropped_particles") == 0 and h.out_of_bounds == 0
+        assert rel_l2(get(h, "x"), o.field("x")) < 1e-5
+        assert rel_l2(get(h, "v"), o.field("v")) < 1e-4
+        out[fuse] = get(h, "x")
+    assert rel_l2(out[1], out[0]) < 1e-6    # (slow-path fp32 atomics are order-dependent: not bit-identical)
+
+
+def test_packed_scatter_parity(hip_device):
+    """set_scalar "scatter_bits" 32: two 32-bit fixed-point sums per LDS atomic (2 atomics per node instead of 4).  The sums
+    stay exact integers (bit-reproducible), the quantum grows from 2^-42 to 2^-22 of the largest contribution bound in a
+    tile.  Required: the same particle-level parity as the exact mode (x, F 1e-4 outright; v, C within the float32
+    oracle's own drift), momentum-weighted grid parity, and the documented loss: nodes whose whole mass is below the
+    quantum (stencil corners at a free surface) are dropped -- their share of the grid's momentum is reported."""
+    sc = mpm_ball_scene(20000, seed=1)
+    n = 20000
+    rng = np.random.default_rng(0)
+    v0 = (0.5 * rng.normal(size=(n, 3))).astype(np.float32)
+    C0 = (2.0 * rng.normal(size=(n, 3, 3))).astype(np.float32)
+    Ft0 = (np.eye(3) + 0.03 * rng.normal(size=(n, 3, 3))).astype(np.float32)
+    h, o = make_hip(sc), make_oracle(sc, "f32")
+    h._set_scalar("scatter_bits", 32)
+    h.set_field("v", v0); h.set_field("C", C0.reshape(n, 9)); h.set_field("F_trial", Ft0.reshape(n, 9))
+    o.field("v")[:] = v0; o.field("C")[:] = C0; o.field("F_trial")[:] = Ft0
+    dt = sc["dt"]
+    o.phase("zero_grid"); o.phase("pre_p2g", dt); o.phase("compute_stress", dt); o.phase("p2g", dt)
+    h.phase(0, dt)
+    m_h, m_o = get(h, "grid_m").astype(np.float64), o.field("grid_m").astype(np.float64)
+    p_h, p_o = get(h, "grid_v_in").astype(np.float64), o.field("grid_v_in").astype(np.float64)
+    assert rel_l2(m_h, m_o) < 1e-5 and rel_l2(p_h, p_o) < 1e-4
+    assert abs(m_h.sum() - m_o.sum()) / m_o.sum() < 1e-6                       # mass conserved through the rounding
+    assert np.abs(p_h.sum(axis=(0, 1, 2)) - p_o.sum(axis=(0, 1, 2))).max() / np.abs(p_o).sum() < 1e-6
+    o.phase("grid_update", dt); o.phase("grid_damping"); o.phase("apply_bcs", dt)
+    h.phase(1, dt)
+    gv_h, gv_o = get(h, "grid_v_out").astype(np.float64), o.field("grid_v_out").astype(np.float64)
+    m_p = float(o.field("mass").max())
+    heavy = m_o > 1e-3 * m_p          # nodes a particle sees with a weight that matters
+    # momentum-weighted: what G2P hands back to the particles is sum_i w_ip v_i, and w_ip ~ m_i / m_p
+    werr = np.linalg.norm((m_o[..., None] * (gv_h - gv_o))) / np.linalg.norm(m_o[..., None] * gv_o)
+    lost = (m_o > 1e-15) & (np.abs(gv_h).sum(-1) == 0) & (np.abs(gv_o).sum(-1) > 0)
+    print(f"packed scatter: heavy nodes {heavy.sum()} rel-L2 {rel_l2(gv_h[heavy], gv_o[heavy]):.2e}; momentum-weighted error over all nodes {werr:.2e}; "
+          f"nodes quantised to zero mass {lost.sum()} of {(m_o > 1e-15).sum()}, carrying {m_o[lost].sum() / m_o.sum():.2e} of the mass")
+    assert rel_l2(gv_h[heavy], gv_o[heavy]) < 1e-4
+    assert werr < 1e-5
+    assert m_o[lost].sum() / m_o.sum() < 1e-6
+    o.phase("g2p", dt)
+    h.phase(2, dt)
+    assert rel_l2(get(h, "x"), o.field("x")) < 1e-6
+    assert rel_l2(get(h, "v"), o.field("v")) < 1e-4
+    assert rel_l2(get(h, "C").reshape(n, 3, 3), o.field("C")) < 1e-4
+    assert rel_l2(get(h, "F_trial").reshape(n, 3, 3), o.field("F_trial")) < 1e-6
+    # rollouts, same bars as the exact mode
+    for scenario in ("tree", "ball"):
+        sc2 = mpm_ball_scene(20000, seed=2, scenario=scenario)
+        h2, o32, o64 = make_hip(sc2), make_oracle(sc2, "f32"), make_oracle(sc2, "f64")
+        h2._set_scalar("scatter_bits", 32)
+        h2.run(sc2["dt"], 200)
+        o32.run(sc2["dt"], 200); o64.run(sc2["dt"], 200)
+        _assert_rollout_parity(h2, o32, o64, sc2, "packed-" + scenario)
+        h3 = make_hip(sc2)
+        h3._set_scalar("scatter_bits", 32)
+        h3.run(sc2["dt"], 200)
+        assert np.array_equal(get(h2, "x"), get(h3, "x")) and np.array_equal(get(h2, "v"), get(h3, "v"))   # bit-reproducible
+
+
+def test_inverted_particles_take_the_svd_route(hip_device):
+    """Jelly particles with det F <= 0 (inverted elements): the Newton polar iteration of the fast path does not give
+    U V^T of the proper-rotation SVD there (mpm_math.h: polar_rotation returns false) and the kernel must fall back to
+    svd3, as kirchoff_stress_FCR (mpm_utils.py:10-17) uses wp.svd3 for every particle.  A tenth of the particles start
+    reflected / collapsed along one axis; compared with the float64 oracle after a few substeps (the inverted elements
+    push back violently, so the horizon is short), plus the stress of the very first substep."""
+    sc = mpm_ball_scene(20000, seed=21, scenario="ball")
+    sc["params"] = dict(material="jelly", g=[0.0, 0.0, 0.0], E=2e4, nu=0.3, density=1000.0)
+    n = 20000
+    rng = np.random.default_rng(5)
+    Ft0 = (np.eye(3) + 0.02 * rng.normal(size=(n, 3, 3)))
+    bad = rng.random(n) < 0.1
+    flip = np.diag([1.0, 1.0, -0.6])
+    Ft0[bad] = Ft0[bad] @ flip
+    Ft0[bad & (rng.random(n) < 0.3), :, 1] *= 1e-3          # some nearly rank-deficient on top
+    Ft0 = Ft0.astype(np.float32)
+    assert (np.linalg.det(Ft0.astype(np.float64)) < 0).sum() > 1500
+    # stress of the first substep: the branch under test, before any dynamics amplify differences
+    h0, o0 = make_hip(sc, per_particle=False), make_oracle(sc, "f64", per_particle=False)
+    h0.set_field("F_trial", Ft0.reshape(n, 9)); o0.field("F_trial")[:] = Ft0
+    h0.phase(0, sc["dt"])
+    o0.phase("zero_grid"); o0.phase("pre_p2g", sc["dt"]); o0.phase("compute_stress", sc["dt"])
+    tau_h, tau_o = get(h0, "stress").reshape(n, 3, 3), o0.field("stress")
+    assert np.isfinite(tau_h).all()
+    assert rel_l2(tau_h[bad], tau_o[bad]) < 1e-4
+    assert rel_l2(tau_h[~bad], tau_o[~bad]) < 5e-4          # 2 mu (F - R): cancellation-limited (as in the phase test)
+    h0.phase(1, sc["dt"]); h0.phase(2, sc["dt"])            # (finish the substep: a pending phase-API P2G blocks the handle)
+    h, o32, o64 = make_hip(sc, per_particle=False), make_oracle(sc, "f32", per_particle=False), make_oracle(sc, "f64", per_particle=False)
+    h.set_field("F_trial", Ft0.reshape(n, 9))
+    o32.field("F_trial")[:] = Ft0; o64.field("F_trial")[:] = Ft0
+    h.run(sc["dt"], 10); o32.run(sc["dt"], 10); o64.run(sc["dt"], 10)
+    x_h, F_h = get(h, "x"), get(h, "F_trial").reshape(n, 3, 3)
+    assert np.isfinite(x_h).all() and np.isfinite(F_h).all()
+    d_x = rel_l2(o32.field("x"), o64.field("x")); d_F = rel_l2(o32.field("F_trial"), o64.field("F_trial"))
+    e_x = rel_l2(x_h, o64.field("x")); e_F = rel_l2(F_h, o64.field("F_trial"))
+    print(f"inverted particles: x {e_x:.2e} (oracle f32 drift {d_x:.2e}), F_trial {e_F:.2e} (drift {d_F:.2e}); still inverted: "
+          f"{int((np.linalg.det(F_h.astype(np.float64)) < 0).sum())}")
+    assert e_x < 1e-4 and e_F < max(1e-4, 4 * d_F)
+    assert h.out_of_bounds == 0
 
 
 PLASTIC = [
