@@ -51,6 +51,31 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_f16 dense peak 
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec (6.3 TB/s achievable per the same guide)
 
 
+def gpu_telemetry(index=0):
+    """Shader clock (MHz), socket power (W) and temperature of one GPU, read from sysfs (no subprocess: the readings bracket
+    the timed region).  The conv kernels run power-limited, so a bench line without these cannot be compared
+    across boxes.  Returns {} where the files do not exist."""
+    import glob
+    out = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        hw = cards[min(index, len(cards) - 1)]
+
+        def rd(name):
+            with open(os.path.join(hw, name)) as f:
+                return float(f.read().strip())
+        for key, fname, scale in (("sclk_mhz", "freq1_input", 1e-6), ("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6),
+                                  ("temp_c", "temp1_input", 1e-3)):
+            if key not in out:
+                try:
+                    out[key] = round(rd(fname) * scale, 1)
+                except OSError:
+                    pass
+    except Exception:
+        pass
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,11 +86,14 @@ def parse():
     ap.add_argument("--particles", type=int, default=100_000)
     ap.add_argument("--n-grid", type=int, default=50)
     ap.add_argument("--mpm-substeps", type=int, default=1000)
+    ap.add_argument("--mpm-large-substeps", type=int, default=2000, help="substeps of the 1M-particle leg (BASELINE configs[4]: 2k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-small", action="store_true", help="time the U-Net CPU baseline at 64^3 instead of the headline grid (saves ~1 min)")
     ap.add_argument("--no-mpm", action="store_true")
     ap.add_argument("--no-shipped-shape", action="store_true", help="skip the 64^3 x 768 fp16-grid sub-record")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32-MFMA sub-record of the same U-Net step")
     ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
+    ap.add_argument("--no-unet-256", action="store_true", help="skip the 256^3 x 128 U-Net sub-record (BASELINE configs[4]'s per-GPU grid)")
     ap.add_argument("--dual-stream-diagnostic", action="store_true",
                     help="also time one scene's launches with the two networks on two HIP streams (roofline.avg_launch_ms_dual_stream)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
@@ -148,7 +176,7 @@ class ConvProfiler:
         return agg
 
 
-def bench_unet(args, rank, world, device, precision_override=None, steps=None, warmup=None):
+def bench_unet(args, rank, world, device, precision_override=None, steps=None, warmup=None, device_input=False):
     from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
     D, C = args.grid, args.feature_channels
     n_steps = args.steps if steps is None else steps
@@ -163,7 +191,10 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     if precision_override or args.conv_precision:
         seg.conv_precision = cont.conv_precision = precision_override or args.conv_precision
     precision = seg.conv_precision
-    feat = torch.from_numpy(feature_grid(D, C, seed=100 + rank)).to(device)  # scene i uses seed 100+i
+    if device_input:   # large grids: seeded on the device (numpy needs ~30 s for the 2.1e9 normals of a 256^3 x 128 grid)
+        feat = torch.randn((1, C, D, D, D), generator=torch.Generator(device=device).manual_seed(100 + rank), device=device)
+    else:
+        feat = torch.from_numpy(feature_grid(D, C, seed=100 + rank)).to(device)  # scene i uses seed 100+i
 
     def step(dual_stream=None):
         combined, seg_pred, _, cont_pred = predict_material_field(seg, cont, feat, dual_stream=dual_stream)
@@ -177,11 +208,32 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
         step()
     executor = f"{seg.executor}{'+hip_graph' if seg.use_graph else ''}"
     barrier_sync(world)
+    tele0 = gpu_telemetry(device.index or 0)
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step()
+    tele_mid = gpu_telemetry(device.index or 0)    # while the last steps are still running on the device
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, device)
+    # where a step's time goes: events around each network's forward (one graph replay + the copy of its output) and the
+    # combine, three more scenes right after the timed region
+    parts = {"seg_forward_ms": 0.0, "cont_forward_ms": 0.0, "combine_and_stack_ms": 0.0}
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for _ in range(3):
+        evs[0].record()
+        a = seg(feat)
+        evs[1].record()
+        b = cont(feat)
+        evs[2].record()
+        seg._runner.ops.combine(a[0].contiguous(), b[0].contiguous())
+        evs[3].record()
+        torch.cuda.synchronize()
+        parts["seg_forward_ms"] += evs[0].elapsed_time(evs[1]) / 3
+        parts["cont_forward_ms"] += evs[1].elapsed_time(evs[2]) / 3
+        parts["combine_and_stack_ms"] += evs[2].elapsed_time(evs[3]) / 3
+    parts = {k: round(v, 3) for k, v in parts.items()}
+    parts["telemetry_before"] = tele0
+    parts["telemetry_during"] = tele_mid
     flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
     # dominant kernel: the full-resolution 64->64 3x3x3 conv (82 % of FLOPs are at full resolution).  The timed region above is
     # the product default: each network is ONE pixie_unet_forward call replayed as a captured HIP graph, the two networks back
@@ -238,7 +290,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     conv_ms = sum(v[0] for v in agg.values()) / 2.0
     return dict(seconds=dt, steps=n_steps, voxels=world * n_steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision, executor=executor,
                 conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / 2.0, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
-                kernel_avg=prof.by_variant(), kernel_avg_timed=kernel_avg_timed)
+                kernel_avg=prof.by_variant(), kernel_avg_timed=kernel_avg_timed, step_parts=parts)
 
 
 def bench_shipped_shape(args, device):
@@ -293,19 +345,43 @@ def load_traffic():
         return {}
 
 
-def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag):
+def _mpm_solver(sc, scatter_bits=None):
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
-    sc = mpm_ball_scene(particles, seed=rank, n_grid=n_grid)
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
     apply_scene(s, sc)
+    if scatter_bits:
+        s._set_scalar("scatter_bits", scatter_bits)
+    return s
+
+
+def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatter_bits=None, loop_api=False):
+    """One scene per GPU: `substeps` substeps through run() (the fused step loop), timed with barriers; a short separate pass
+    with HIP events around every launch for the kernel roofline; optionally the reference driver's own loop
+    (gs_simulation.py:633-634: one p2g2p() call per substep, then an export), which the shim defers into the same run()."""
+    sc = mpm_ball_scene(particles, seed=rank, n_grid=n_grid)
+    s = _mpm_solver(sc, scatter_bits)
     s.run(sc["dt"], 50)  # warm-up (includes the cautious first re-binning intervals)
     barrier_sync(world)
     t0 = time.perf_counter()
     s.run(sc["dt"], substeps)
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, device)
+    loop = None
+    if loop_api:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(substeps):
+            s.p2g2p(i, sc["dt"])
+        t_host = time.perf_counter() - t1
+        x = s.export_particle_x_to_torch()      # the per-frame observation: flushes the queued substeps
+        torch.cuda.synchronize()
+        dl = time.perf_counter() - t1
+        loop = {"us_per_substep": 1e6 * dl / substeps, "value": particles * substeps / dl, "unit": "particle-steps/s",
+                "host_us_per_p2g2p_call": 1e6 * t_host / substeps, "vs_run": dl / dt,
+                "what": f"for step in range({substeps}): solver.p2g2p(step, dt); then export_particle_x_to_torch() -- the calls are queued "
+                        "and run as ONE fused run() at the export (pixie_amd/mpm_solver.py)"}
     # separate short pass with per-launch HIP events on the launch stream for the roofline of the fused block kernel
     s.set_profile(True)
     s.run(sc["dt"], 200)
@@ -316,7 +392,8 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag):
     part_bytes = 212.0 * particles
     ach = part_bytes / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
     tr = (load_traffic().get(f"mpm_{tag}_block") or {})
-    roof = {"bound": "hbm", "kernel": "mpm_block_kernel<true,true,5> (fused G2P + stress + P2G, one launch per substep)",
+    bits = int(s._get_scalar("scatter_bits"))
+    roof = {"bound": "hbm", "kernel": f"mpm_block_kernel<true,true,..> (fused G2P + stress + P2G, one launch per substep; {bits}-bit fixed-point scatter)",
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4),
             "traffic": tr.get("hbm_bytes_per_launch"), "traffic_source": "profiles/pmc_traffic.json" if tr else None,
             "avg_launch_ms": round(p_ms, 5), "grid_kernel_ms": round(g_ms, 5), "launches": int(n_launch),
@@ -324,13 +401,48 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag):
     oob = s.out_of_bounds
     finite = bool(torch.isfinite(s.get_field("x")).all())
     ps = world * particles * substeps / dt
-    return {"value": ps, "unit": "particle-steps/s", "substeps": substeps, "us_per_substep": 1e6 * dt / substeps,
-            "config": {"workload": f"{particles} particles, n_grid {n_grid}, grid_lim 2, dt 1e-4, jelly ball, tree scenario "
-                                   "(impulse + ground slab), 1 scene per GPU"},
-            "algorithmic_GBps": alg_bytes * substeps / dt / 1e9,
-            "frac_of_hbm_roofline_per_gpu": alg_bytes * substeps / dt / 1e9 / PEAK_HBM_GBPS,
-            "roofline": roof, "finite": finite, "out_of_bounds": oob,
-            "rebins": int(s._get_scalar("n_rebins")), "slow_path_particle_substeps": int(s._get_scalar("slow_path_particles"))}
+    out = {"value": ps, "unit": "particle-steps/s", "substeps": substeps, "us_per_substep": 1e6 * dt / substeps,
+           "config": {"workload": f"{particles} particles, n_grid {n_grid}, grid_lim 2, dt 1e-4, jelly ball, tree scenario "
+                                  "(impulse + ground slab), 1 scene per GPU", "scatter_bits": bits},
+           "algorithmic_GBps": alg_bytes * substeps / dt / 1e9,
+           "frac_of_hbm_roofline_per_gpu": alg_bytes * substeps / dt / 1e9 / PEAK_HBM_GBPS,
+           "roofline": roof, "finite": finite, "out_of_bounds": oob,
+           "rebins": int(s._get_scalar("n_rebins")), "slow_path_particle_substeps": int(s._get_scalar("slow_path_particles"))}
+    if loop is not None:
+        out["p2g2p_loop"] = loop
+    return out
+
+
+def bench_mpm_multi_scene(args, device, particles, n_grid, substeps, n_scenes):
+    """BASELINE configs[3] runs a batch of scenes.  One 100 k-particle scene fills 41 % of the chip's workgroup slots and its
+    launches are latency-bound, so several independent scenes on their own HIP streams (one host thread each: the launch
+    loop is a foreign call that releases the GIL) share the GPU.  Reports aggregate particle-steps/s for this GPU."""
+    import threading
+    scenes = [mpm_ball_scene(particles, seed=10 + i, n_grid=n_grid) for i in range(n_scenes)]
+    solvers = [_mpm_solver(sc) for sc in scenes]
+    streams = [torch.cuda.Stream(device) for _ in range(n_scenes)]
+
+    def work(i, n):
+        torch.cuda.set_device(device)
+        with torch.cuda.stream(streams[i]):
+            solvers[i].run(scenes[i]["dt"], n)
+
+    def run_all(n):
+        th = [threading.Thread(target=work, args=(i, n)) for i in range(n_scenes)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+
+    run_all(50)
+    t0 = time.perf_counter()
+    run_all(substeps)
+    dt = time.perf_counter() - t0
+    finite = all(bool(torch.isfinite(s.get_field("x")).all()) for s in solvers)
+    return {"value": n_scenes * particles * substeps / dt, "unit": "particle-steps/s", "scenes": n_scenes, "substeps": substeps,
+            "us_per_substep_per_scene": 1e6 * dt / substeps, "finite": finite,
+            "config": {"workload": f"{n_scenes} independent scenes of {particles} particles (n_grid {n_grid}) on {n_scenes} HIP streams of one GPU"}}
 
 
 def bench_field_transfer(args, device):
@@ -371,15 +483,15 @@ def bench_field_transfer(args, device):
 def cpu_baselines(args):
     """CPU baselines on this box's host cores, bounded samples (reported next to the GPU numbers, not a target):
     U-Net: oracle/unet_oracle.py on PyTorch's CPU kernels -- the reference's own modules do not exist on the GPU box
-      (/root/reference is absent there); the oracle is pinned bit-for-bit to them (tests/golden).  Timed at 64^3 (one
-      128^3 pair needs ~1 min and 25 GB), so the voxels/s figure is the 64^3 one; the conv work per voxel is the same.
+      (/root/reference is absent there); the oracle is pinned bit-for-bit to them (tests/golden).  Timed at the headline
+      grid (one 128^3 pair: ~1 min, 25 GB of host memory); --cpu-baseline-small times 64^3 instead.
     MPM: both restatements -- oracle/mpm_vectorised.py (torch CPU tensors, multi-core) and oracle/mpm_oracle.c (scalar C,
       one core) -- at the bench's 100 k-particle scene, and the vectorised one at the 1 M scene."""
     from oracle import unet_oracle
     from oracle.mpm_oracle import OracleMPM
     from oracle.mpm_vectorised import VectorisedMPM
     out = {}
-    Dc = 64 if args.grid >= 64 else args.grid
+    Dc = args.grid if not args.cpu_baseline_small else min(args.grid, 64)
     feat = feature_grid(Dc, args.feature_channels, seed=100)
     nets = []
     for oc, ws in ((8, 0), (3, 1000)):
@@ -390,8 +502,8 @@ def cpu_baselines(args):
         unet_oracle.unet_forward(sd, cfg, feat)
     dt = time.perf_counter() - t0
     out["unet"] = {"value": Dc ** 3 / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"{Dc}^3x{args.feature_channels} grid (NOT the {args.grid}^3 headline size: 1/{(args.grid // Dc) ** 3} of its voxels, same "
-                             f"work per voxel), SegmentationUNet+RegressionUNet forward once, oracle/unet_oracle.py on PyTorch CPU "
+                   "sample": f"{Dc}^3x{args.feature_channels} grid (" + ("the headline size" if Dc == args.grid else f"NOT the {args.grid}^3 headline size: 1/{(args.grid // Dc) ** 3} of its voxels, same work per voxel")
+                             + f"), SegmentationUNet+RegressionUNet forward once, oracle/unet_oracle.py on PyTorch CPU "
                              f"({dt:.1f} s; the reference's modules are not present on this box, the oracle is pinned to them)"}
 
     def timed(make, n, n_grid, steps, what, cores):
@@ -492,11 +604,28 @@ def main():
         u32 = None
         if not args.no_exact_f32 and u["precision"] == "f16x3":
             u32 = bench_unet(args, rank, world, device, precision_override="f32", steps=min(args.steps, 3), warmup=1)
-        m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k")
-        # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120): where the HBM roofline fraction is meaningful
-        m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, 300, "1m")
+        m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k", loop_api=True)
+        # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120, 2000 substeps): where the HBM roofline fraction is meaningful
+        m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, args.mpm_large_substeps, "1m")
+        other_bits = {64: 32, 32: 64}
+        m_alt = m_large_alt = m_multi = None
+        if rank == 0 and world == 1 and not args.no_mpm:
+            # the other scatter mode beside the default (exact 64-bit <-> packed 32-bit pairs), and the multi-scene leg
+            m_alt = bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k",
+                              scatter_bits=other_bits[m["config"]["scatter_bits"]])
+            if m_large is not None:
+                m_large_alt = bench_mpm(args, rank, world, device, 1_000_000, 120, min(args.mpm_large_substeps, 500), "1m",
+                                        scatter_bits=other_bits[m_large["config"]["scatter_bits"]])
+            m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
         ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
         shipped = bench_shipped_shape(args, device) if (rank == 0 and world == 1 and not args.no_shipped_shape) else None
+        # BASELINE configs[4]'s per-GPU U-Net workload: 256^3 x 128 (217 TFLOP per scene, ~60 GiB of workspace)
+        u256 = None
+        if rank == 0 and world == 1 and not args.no_unet_256 and u["precision"] == "f16x3" and args.grid == 128:
+            torch.cuda.empty_cache()
+            big = argparse.Namespace(**{**vars(args), "grid": 256, "feature_channels": 128, "dual_stream_diagnostic": False})
+            u256 = bench_unet(big, rank, world, device, steps=2, warmup=0, device_input=True)
+            torch.cuda.empty_cache()
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baselines(args)
@@ -519,6 +648,7 @@ def main():
                        "executor": u["executor"] + " (one pixie_unet_forward call per network; graph replays of >= 128^3 grids run back to back on one stream)"},
             "unet_tflops": u["flops_scene"] * world * u["steps"] / u["seconds"] / 1e12,
             "unet_conv_ms_per_step": u["conv_ms_per_step"],
+            "step_decomposition": u["step_parts"],
             "roofline": u["roofline"],
         }
         if u32 is not None:
@@ -527,12 +657,24 @@ def main():
                                  "unet_tflops": u32["flops_scene"] * world * u32["steps"] / u32["seconds"] / 1e12, "roofline": u32["roofline"]}
         if m is not None:
             line["mpm"] = m
+            if m_alt is not None:
+                line["mpm"]["other_scatter_mode"] = {k: m_alt[k] for k in ("value", "us_per_substep", "config", "frac_of_hbm_roofline_per_gpu", "roofline", "finite")}
+            if m_multi is not None:
+                line["mpm"]["multi_scene"] = m_multi
         if m_large is not None:
             line["mpm_1m"] = m_large
+            if m_large_alt is not None:
+                line["mpm_1m"]["other_scatter_mode"] = {k: m_large_alt[k] for k in ("value", "substeps", "us_per_substep", "config", "frac_of_hbm_roofline_per_gpu", "roofline", "finite")}
         if ft is not None:
             line["field_to_particles"] = ft
         if shipped is not None:
             line["shipped_shape_64x768"] = shipped
+        if u256 is not None:
+            line["unet_256x128"] = {"workload": "256^3 x 128 feature grid -> SegmentationUNet+RegressionUNet forward (+combine), 1 scene per step (BASELINE configs[4] per-GPU grid)",
+                                    "value": u256["voxels"] / u256["seconds"], "unit": "voxels/s", "steps": u256["steps"],
+                                    "ms_per_step": 1e3 * u256["seconds"] / u256["steps"],
+                                    "unet_tflops": u256["flops_scene"] * u256["steps"] / u256["seconds"] / 1e12, "roofline": u256["roofline"],
+                                    "step_decomposition": u256["step_parts"], "peak_device_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
         if cpu is not None:
             line["cpu_baseline"] = cpu["unet"]
             if "mpm" in line:

@@ -68,12 +68,6 @@ struct MpmPtrs {
     const int2* nbr_table;       // per active block (same order): [0] = (block id, 0), [1..27] = blk_items of its 27 neighbours
     unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles,
                                  // [2] slow-path particles dropped because they had left every active block
-    // ---- grid update in the tail of the block kernel (F_TAIL): see grid_tail()
-    float4* gout_next;           // the grid-velocity array the tail writes (ping-pong partner of gout)
-    int* arrive;                 // per active block: work items that have published a tile covering it (reset by the last one)
-    const int* expected;         // per active block: work items of its 27 neighbours = arrivals that complete it
-    const int* blk_slot;         // per block: its position in active_list / nbr_table (-1: inactive)
-    const int* nbr_slots;        // per active block: blk_slot of its 27 neighbours (-1: outside the grid)
 };
 
 struct StepParams {
@@ -291,21 +285,15 @@ __device__ __noinline__ void g2p_gather_global(const float4* __restrict__ gout, 
 }
 
 __device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int nbk, int ng, Stencil st,
-                                                const float* mvAT /* mv[3], A[9], T[9] */, float mass, int own_block) {
+                                                const float* mvAT /* mv[3], A[9], T[9] */, float mass) {
     const size_t r0 = ((size_t)st.base[0] * ng + st.base[1]) * ng + st.base[2];
     // the 3x3x3 stencil touches at most 2 blocks per axis: tell the grid kernel they hold gin contributions.  The grid
     // kernel only visits ACTIVE blocks (particles within one block at the last re-binning); a particle that has left
     // all of them drifted >= 3 cells since then although the re-binning cadence is set to keep the drift below half a
     // cell (rebin()) -- it is dropped and counted, like a particle that leaves the grid.
-    // With the grid update in the block kernel's tail (own_block >= 0) the node blocks written here must also be among
-    // the 27 neighbours of this work item's block: only those wait for this item's arrival before they are reduced.
     bool reachable = true;
     for (int c = 0; c < 8; ++c) {
         const int bx = (st.base[0] + 2 * (c >> 2)) / kBS, by = (st.base[1] + 2 * ((c >> 1) & 1)) / kBS, bz = (st.base[2] + 2 * (c & 1)) / kBS;
-        if (own_block >= 0) {
-            const int oz = own_block % nbk, oy = (own_block / nbk) % nbk, ox = own_block / (nbk * nbk);
-            if (abs(bx - ox) > 1 || abs(by - oy) > 1 || abs(bz - oz) > 1) { reachable = false; continue; }
-        }
         reachable = reachable && (atomicOr(&blk_flags[(bx * nbk + by) * nbk + bz], 2) & 1);
     }
     if (!reachable) return false;
@@ -565,34 +553,20 @@ __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
 // kernel variants (FL)
 constexpr int F_TRACE = 1;    // phase stamps + the ablation switches of StepParams.trace (timing studies only)
 constexpr int F_PACK32 = 2;   // packed 32-bit scatter (above)
-constexpr int F_TAIL = 4;     // grid update in the kernel's tail (grid_tail below): ONE launch per substep
 constexpr int F_WIDE = 8;     // no scheduling barriers: for scenes too small to fill the chip, where latency, not issue, binds
-
-template <int RB, bool SC>
-__device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, int slot, float4* dst);
-
-// 16-byte store that is written through to memory (sc0 sc1): what another CU's sc0 sc1 load is guaranteed to see once this
-// wave's vmcnt has drained -- no L2 write-back fence needed (MI355X_MICROARCH.md, inter-workgroup visibility)
-__device__ __forceinline__ void store_through(float4* p, float4 v) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(w) : "memory");
-}
 
 // OCC = waves per SIMD the register allocation is held to (launch_bounds).  Built without the SLP vectoriser (see
 // pixie_amd/build.py) the kernel needs 96 VGPRs -> 5 waves per SIMD with no spills (with it: 168 VGPRs, 3 waves, and
 // 20 % slower); 6 -> 80 VGPRs with ~20 spilled dwords (measured slower: 86 vs 81 us at 1 M particles).  Chosen at run
 // time (set_scalar "occupancy"), same arithmetic.
 template <bool DO_G2P, bool DO_P2G, int OCC, int FL>
-__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms, BCSet bcs) {
+__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
     constexpr bool PACK = (FL & F_PACK32) != 0;
     constexpr bool TRACE = (FL & F_TRACE) != 0;
-    constexpr bool TAIL = (FL & F_TAIL) != 0;
     constexpr bool SCHED = (FL & F_WIDE) == 0;
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
     __shared__ unsigned long long ta[PACK ? 2 : 4][kTN];  // (m*v.xyz, m) of this work item as scaled integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
-    __shared__ int s_done;
     const int4 it = S.items[blockIdx.x];
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;   // = the work-item capacity of the current binning (256; 128 on request)
@@ -603,7 +577,6 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     Preload L;
     L.selection = 1;
     if (tid < it.z) preload_particle<DO_G2P, DO_P2G>(S, it.y + tid, L);   // in flight while the tile is staged
-    if (TAIL && tid == 0) s_done = 0;
     for (int idx = tid; idx < kTN; idx += nthr) {
         if (DO_G2P) {
             const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
@@ -652,7 +625,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
                 for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) { mvAT[3 + k] = in.A.m[k]; mvAT[12 + k] = in.T.m[k]; }
-                if (!p2g_scatter_global(S.gin, S.blk_flags, S.nbk, ng, st, mvAT, in.mass, TAIL ? it.x : -1)) atomicAdd(S.oob + 2, 1ull);
+                if (!p2g_scatter_global(S.gin, S.blk_flags, S.nbk, ng, st, mvAT, in.mass)) atomicAdd(S.oob + 2, 1ull);
                 in.active = false;
             }
         }
@@ -718,43 +691,13 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
                 o = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP), from_fixed(ta[3][idx], iM));
             }
             float4* d = dst + staged_index(idx >> 6, (idx >> 3) & 7, idx & 7);
-            if (TAIL) store_through(d, o);
-            else *d = o;
+            *d = o;
         }
     PX_MPM_STAMP(5);
     if (TRACE && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
         g_mpm_trace[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-
-    if (TAIL) {
-        // ---- grid update in the tail.  A node block (4x4x4 nodes) is complete when every work item of its 27 neighbour
-        // blocks has published its tile; the item that makes the count reach `expected` updates that block (normalise,
-        // gravity, damping, BCs -> gout_next).  Nobody ever waits: the protocol is a last-arriver reduction (as in a split-K
-        // epilogue), so it cannot deadlock whatever the dispatch order.  Visibility: tiles are stored write-through
-        // (sc0 sc1) and each wave drains its vmcnt before it counts itself in; the wave that finds the other waves of its
-        // work item already counted raises the device-scope counters; the gather reads with sc0 sc1 loads.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int lane = tid & 63;
-        int prev = 0;
-        if (lane == 0) prev = atomicAdd(&s_done, 1);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        if (prev != (nthr >> 6) - 1) return;
-        const int my_slot = S.blk_slot[it.x];
-        int nslot = -1, old = -2, want = -1;
-        if (lane < 27) nslot = S.nbr_slots[(size_t)my_slot * 27 + lane];
-        if (nslot >= 0) {
-            want = S.expected[nslot];
-            old = __hip_atomic_fetch_add(&S.arrive[nslot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned long long todo = __ballot(nslot >= 0 && old + 1 == want);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int slot = __shfl(nslot, src);
-            if (lane == 0) S.arrive[slot] = 0;    // nobody touches it again before the next launch
-            grid_block_update<1, true>(S, sp, bcs, slot, S.gout_next);
-        }
-    }
 }
+
 // ------------------------------------------------------------------ re-binning (counting sort by block)
 __device__ __forceinline__ int block_of(const MpmPtrs& S, int p) {
     int b[3];
@@ -881,8 +824,7 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
 // ones the grid kernel is launched for (workgroup dispatch alone costs ~10 us for the 27000 blocks of a 120^3 grid).
 __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restrict__ counts, int* __restrict__ blk_flags,
                                                               int* __restrict__ active_list, int* __restrict__ n_active, int nbk,
-                                                              const int2* __restrict__ blk_items, int2* __restrict__ nbr_table,
-                                                              int* __restrict__ blk_slot) {
+                                                              const int2* __restrict__ blk_items, int2* __restrict__ nbr_table) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbk * nbk * nbk) return;
     const int bz = b % nbk, by = (b / nbk) % nbk, bx = b / (nbk * nbk);
@@ -895,10 +837,9 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
                     active = active || counts[(x * nbk + y) * nbk + z] > 0;
             }
     blk_flags[b] = active ? 1 : 0;
-    if (!active) { blk_slot[b] = -1; return; }
+    if (!active) return;
     const int slot = atomicAdd(n_active, 1);
     active_list[slot] = b;
-    blk_slot[b] = slot;
     // everything the grid kernel needs to find this block's tiles, in one 224-byte row: one memory round trip there
     // instead of active_list -> blk_items -> tiles
     int2* row = nbr_table + (size_t)slot * 28;
@@ -908,26 +849,6 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
         const bool in = (unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk;
         row[1 + q] = in ? blk_items[(x * nbk + y) * nbk + z] : make_int2(0, 0);
     }
-}
-
-// Tables of the tail grid update (grid_tail in the block kernel): for every active block the slots of its 27 neighbours,
-// the number of work items whose tiles cover it (= arrivals that complete it), and a cleared arrival counter.
-__global__ __launch_bounds__(256) void bin_tail_tables_kernel(const int* __restrict__ active_list, const int* __restrict__ n_active, int nbk,
-                                                              const int* __restrict__ blk_slot, const int2* __restrict__ nbr_table,
-                                                              int* __restrict__ nbr_slots, int* __restrict__ expected, int* __restrict__ arrive) {
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot >= *n_active) return;
-    const int b = active_list[slot];
-    const int bz = b % nbk, by = (b / nbk) % nbk, bx = b / (nbk * nbk);
-    int total = 0;
-    for (int q = 0; q < 27; ++q) {
-        const int x = bx + q / 9 - 1, y = by + (q / 3) % 3 - 1, z = bz + q % 3 - 1;
-        const bool in = (unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk;
-        nbr_slots[(size_t)slot * 27 + q] = in ? blk_slot[(x * nbk + y) * nbk + z] : -1;
-        total += nbr_table[(size_t)slot * 28 + 1 + q].y;
-    }
-    expected[slot] = total;
-    arrive[slot] = 0;
 }
 
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
@@ -1010,9 +931,8 @@ __device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By
     }
     return mine;
 }
-// RB = items per candidate block fetched in one go (8 x RB tile loads in flight); SC = read with sc0 sc1 (device-coherent)
-// buffer loads: the tail of the block kernel gathers tiles other workgroups published in the SAME launch.
-template <int RB, bool SC>
+// RB = items per candidate block fetched in one go (8 x RB tile loads in flight)
+template <int RB>
 __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
     const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
     unsigned off[8];   // in float4 units from S.part
@@ -1028,8 +948,6 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
         cnt[c] = n;
         maxc = max(maxc, n);
     }
-    __amdgpu_buffer_rsrc_t rs;
-    if (SC) rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.part, 0, 0x7fffffff, 0x00020000);   // raw buffer, 32-bit byte offsets (host checks the size)
     // up to RB items per block in one go: all 8 x RB tile loads of a node are issued before the first is consumed
     for (int r0 = 0; r0 < maxc; r0 += RB) {
         float4 q[RB][8];
@@ -1039,14 +957,7 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
             for (int c = 0; c < 8; ++c) {
                 const bool on = r0 + r < cnt[c];
                 const unsigned o = off[c] + (unsigned)(r0 + r) * kTN;
-                if (SC) {
-                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rs, on ? (int)(o * 16u) : 0, 0, 0x11);   // aux: sc0 | sc1
-                    q[r][c] = on ? make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w))
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    q[r][c] = on ? S.part[o] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                q[r][c] = on ? S.part[o] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -1072,9 +983,8 @@ __device__ __forceinline__ float4 finish_node(const MpmPtrs& S, const StepParams
 }
 
 // One WAVE updates the 4x4x4 nodes of active block `slot`: gather the staged tiles (+ what slow-path particles added to gin),
-// normalise, gravity, damping, BCs -> dst.  Called by mpm_grid_block_kernel (one wave per block, after the block kernel) and,
-// with SC, from the tail of the block kernel by the work item that completed the block.
-template <int RB, bool SC>
+// normalise, gravity, damping, BCs -> dst.
+template <int RB>
 __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, int slot, float4* dst) {
     const int lane = threadIdx.x & 63;
     // one coalesced row: block id + the work items of the 27 neighbours (lane q holds neighbour q)
@@ -1084,24 +994,15 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
     mine.x = __shfl(row.x, (lane + 1) & 63); mine.y = __shfl(row.y, (lane + 1) & 63);
     const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
     // bit 0: active (set at re-binning); bit 1: slow-path particles added fp32 atomics into gin here
-    const int flag = SC ? __hip_atomic_load(&S.blk_flags[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.blk_flags[blk];
+    const int flag = S.blk_flags[blk];
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
     const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
     const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
-    float4 g = gather_node<RB, SC>(S, mine, lx, ly, lz, make_float4(0.f, 0.f, 0.f, 0.f));   // does not wait for the flag
+    float4 g = gather_node<RB>(S, mine, lx, ly, lz, make_float4(0.f, 0.f, 0.f, 0.f));   // does not wait for the flag
     if (flag & 2) {
         if (inside) {
-            float4 q;
-            if (SC) {   // the atomics went to memory behind the L2s; read them there
-                float* cell = reinterpret_cast<float*>(S.gin + idx);
-                q.x = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q.y = __hip_atomic_load(cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q.z = __hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q.w = __hip_atomic_load(cell + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                q = S.gin[idx];
-            }
+            const float4 q = S.gin[idx];
             g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
             S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
@@ -1117,7 +1018,7 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
 // parameters of the last update, which for a massless node is just the BCs on v = 0.
 __global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
     if (mode == 0) {
-        grid_block_update<4, false>(S, sp, bcs, (int)blockIdx.x, S.gout);
+        grid_block_update<4>(S, sp, bcs, (int)blockIdx.x, S.gout);
         return;
     }
     const int blk = (int)blockIdx.x;
@@ -1138,7 +1039,7 @@ __global__ __launch_bounds__(64) void grid_export_pending_kernel(MpmPtrs S, floa
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) g = S.gin[idx];
-    g = gather_node<4, false>(S, neighbour_items(S, Bx, By, Bz), lx, ly, lz, g);
+    g = gather_node<4>(S, neighbour_items(S, Bx, By, Bz), lx, ly, lz, g);
     if (!inside) return;
     if (what == 0) out[idx] = g.w;
     else { out[3 * idx] = g.x; out[3 * idx + 1] = g.y; out[3 * idx + 2] = g.z; }
@@ -1375,15 +1276,9 @@ struct pixie_mpm {
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
     int2* nbr_table = nullptr;               // 28 int2 per active block (see MpmPtrs)
-    int *arrive = nullptr, *expected = nullptr, *blk_slot = nullptr, *nbr_slots = nullptr;   // tail grid update (MpmPtrs)
-    float4* gout2 = nullptr;                 // ping-pong partner of S.gout
-    int fuse_grid = 1;                       // grid update in the tail of the block kernel: one launch per substep (set_scalar "fuse_grid")
-    bool tail_ok = true;                     // the staged tiles fit the 31-bit offsets of the tail's buffer loads
     int scatter_bits = 64;                   // 64: exact fixed point (4 LDS atomics per node); 32: packed pairs (2 per node)
     int wide = -1;                           // -1 auto: the latency-optimised variant when the scene cannot fill the chip; 0/1 forced
     int n_cus = 256;
-    bool grid_in_tail = false;               // the last P2G launch also did its grid update (launch_grid then only advances the BCs)
-    bool profile_split = false;              // set_scalar "profile" 2: time block and grid kernels separately (no tail fusion)
     int n_active = 0;
     bool gout_sparse = false;                // inactive blocks of gout are stale (refreshed on export)
     StepParams last_grid_sp{};
@@ -1420,7 +1315,6 @@ void bind_rows(pixie_mpm* h) {
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
     S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n;
     S.items = h->items; S.part = h->part; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
-    S.arrive = h->arrive; S.expected = h->expected; S.blk_slot = h->blk_slot; S.nbr_slots = h->nbr_slots;
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -1439,9 +1333,7 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, h->item_cap);
     PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 1, 0, sizeof(int), st));
     hipLaunchKernelGGL(bin_mark_active_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->counts, h->blk_flags, h->active_list,
-                       h->d_n_items + 1, S.nbk, h->blk_items, h->nbr_table, h->blk_slot);  // (rewrites every flag: no slow-path writes are pending here)
-    hipLaunchKernelGGL(bin_tail_tables_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->active_list, h->d_n_items + 1, S.nbk,
-                       h->blk_slot, h->nbr_table, h->nbr_slots, h->expected, h->arrive);
+                       h->d_n_items + 1, S.nbk, h->blk_items, h->nbr_table);  // (rewrites every flag: no slow-path writes are pending here)
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
     // keys/rank are free again: reuse them as the local kernel's scratch
     hipLaunchKernelGGL(bin_local_order_kernel, dim3((unsigned)h->nblocks), dim3(256), 0, st, S, h->counts, h->offsets, h->order, h->keys,
@@ -1558,26 +1450,18 @@ void advance_bcs(pixie_mpm* h, double dt) {
     }
 }
 
-// the grid update can ride in the tail of a P2G launch when one launch carries every BC and the tiles are addressable
-bool tail_possible(const pixie_mpm* h) {
-    return h->fuse_grid && h->tail_ok && h->bcs_dev.size() <= (size_t)kMaxBCPerLaunch && !h->profile_split;
-}
-
 template <bool G, bool P, int OCC, int FL>
-void launch_block(const pixie_mpm* h, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms, const BCSet& bcs) {
-    hipLaunchKernelGGL((mpm_block_kernel<G, P, OCC, FL>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms, bcs);
+void launch_block(const pixie_mpm* h, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms) {
+    hipLaunchKernelGGL((mpm_block_kernel<G, P, OCC, FL>), grid, dim3(h->item_cap), 0, st, h->S, sp, pms);
 }
-// FL without F_WIDE / F_TRACE: the four (packed, tail) combinations
+// exact (64-bit) or packed (32-bit pairs) scatter
 template <bool G, bool P, int OCC, int BASE>
-void launch_block_pt(const pixie_mpm* h, bool pack, bool tail, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms, const BCSet& bcs) {
-    if (pack && tail) launch_block<G, P, OCC, BASE | F_PACK32 | F_TAIL>(h, grid, st, sp, pms, bcs);
-    else if (pack) launch_block<G, P, OCC, BASE | F_PACK32>(h, grid, st, sp, pms, bcs);
-    else if (tail) launch_block<G, P, OCC, BASE | F_TAIL>(h, grid, st, sp, pms, bcs);
-    else launch_block<G, P, OCC, BASE>(h, grid, st, sp, pms, bcs);
+void launch_block_p(const pixie_mpm* h, bool pack, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms) {
+    if (pack) launch_block<G, P, OCC, BASE | F_PACK32>(h, grid, st, sp, pms);
+    else launch_block<G, P, OCC, BASE>(h, grid, st, sp, pms);
 }
 
-// `tail`: do the grid update of this P2G in the same launch (the caller checked tail_possible)
-int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st, bool tail = false) {
+int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st) {
     // (never while staged tiles are waiting for the grid kernel: the work list they are indexed by must not change)
     if (!h->pending_p2g && (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval)))
         if (rebin(h, st)) return 1;
@@ -1601,8 +1485,6 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         for (int k = 0; k < pms.n; ++k) pms.pm[k] = ordered[k];
     }
     if (h->n_items == 0) return 0;  // no particles binned (n_particles > 0 always gives >= 1 item)
-    tail = tail && p2g;
-    const BCSet bcs = tail ? make_bcset(h, 0) : BCSet{};
     const bool pack = h->scatter_bits == 32;
     // Latency-optimised variant (no scheduling barriers, register budget of 2 waves per SIMD): when the whole work list is
     // resident at once with room to spare (<= 2 work items per CU) nothing is gained from occupancy and the launch lasts
@@ -1614,24 +1496,21 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
     if (g2p && p2g && fused_mods) {
-        if (h->trace) {
-            if (pack) launch_block<true, true, 5, F_TRACE | F_PACK32>(h, grid, st, sp, pms, bcs);
-            else launch_block<true, true, 5, F_TRACE>(h, grid, st, sp, pms, bcs);
-            tail = false;
-        } else if (wide) launch_block_pt<true, true, 2, F_WIDE>(h, pack, tail, grid, st, sp, pms, bcs);
-        else if (h->occupancy >= 6 && !pack && !tail) launch_block<true, true, 6, 0>(h, grid, st, sp, pms, bcs);
-        else launch_block_pt<true, true, 5, 0>(h, pack, tail, grid, st, sp, pms, bcs);
+        if (h->trace) launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms);
+        else if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
+        else if (h->occupancy >= 6 && !pack) launch_block<true, true, 6, 0>(h, grid, st, sp, pms);
+        else launch_block_p<true, true, 5, 0>(h, pack, grid, st, sp, pms);
     } else {
         if (g2p) {
             PModSet none{};
-            launch_block<true, false, 5, 0>(h, grid, st, sp, none, BCSet{});
+            launch_block<true, false, 5, 0>(h, grid, st, sp, none);
         }
         if (p2g) {
             if (!fused_mods) {
                 for (const PModDev& m : ordered)
                     hipLaunchKernelGGL(pmod_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, m);
             }
-            launch_block_pt<false, true, 5, 0>(h, pack, tail, grid, st, sp, pms, bcs);
+            launch_block_p<false, true, 5, 0>(h, pack, grid, st, sp, pms);
         }
     }
     if (e0) {
@@ -1639,25 +1518,11 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         h->ev_particle.emplace_back(e0, e1);
     }
     PX_CHECK_HIP(hipGetLastError());
-    if (p2g && !tail) h->pending_p2g = true;
-    if (p2g && tail) {   // the launch wrote the new grid velocities into the partner array
-        std::swap(h->S.gout, h->S.gout_next);
-        h->gout_sparse = true;
-        h->last_grid_sp = sp;
-        h->last_grid_bcs.assign(h->bcs_dev.begin(), h->bcs_dev.end());
-        h->grid_in_tail = true;
-    } else if (p2g) {
-        h->grid_in_tail = false;
-    }
+    if (p2g) h->pending_p2g = true;
     return 0;
 }
 
 int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
-    if (h->grid_in_tail) {   // already done by the P2G launch
-        h->grid_in_tail = false;
-        advance_bcs(h, dt);
-        return 0;
-    }
     const long total = (long)h->S.ng * h->S.ng * h->S.ng;
     const int blocks = cdiv(total, 256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1697,7 +1562,7 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
     return 0;
 }
 
-// Everything whose size depends on n_grid: the grid arrays, the block tables and the work list / staged tiles.
+// Everything whose size depends on n_grid: the two grid arrays, the block tables and the work list / staged tiles.
 // Used by pixie_mpm_create and by pixie_mpm_regrid (set_parameters_dict changing n_grid / grid_lim after the particles
 // were loaded, mpm_solver_warp.py:315-342: the reference re-allocates the grids and recomputes dx, nothing else).
 // The new buffers are allocated first; the old ones are released only when every allocation succeeded, so a failed
@@ -1710,20 +1575,18 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)nblocks, n);   // for the smallest capacity (64)
     std::vector<void*> old;
     old.swap(h->grid_allocs);
-    float4 *gin = nullptr, *gout = nullptr, *gout2 = nullptr, *part = nullptr;
-    int *counts = nullptr, *offsets = nullptr, *active_list = nullptr, *blk_flags = nullptr, *arrive = nullptr, *expected = nullptr, *blk_slot = nullptr, *nbr_slots = nullptr;
+    float4 *gin = nullptr, *gout = nullptr, *part = nullptr;
+    int *counts = nullptr, *offsets = nullptr, *active_list = nullptr, *blk_flags = nullptr;
     int4* items = nullptr;
     int2 *nbr_table = nullptr, *blk_items = nullptr;
     int rc = 0;
-    rc |= dev_alloc(h, &gin, G, true); rc |= dev_alloc(h, &gout, G, true); rc |= dev_alloc(h, &gout2, G, true);
+    rc |= dev_alloc(h, &gin, G, true); rc |= dev_alloc(h, &gout, G, true);
     rc |= dev_alloc(h, &counts, (size_t)nblocks, true); rc |= dev_alloc(h, &offsets, (size_t)nblocks, true);
     rc |= dev_alloc(h, &items, max_items, true);
     rc |= dev_alloc(h, &active_list, (size_t)nblocks, true);
     rc |= dev_alloc(h, &nbr_table, (size_t)nblocks * 28, true);
     rc |= dev_alloc(h, &blk_items, (size_t)nblocks, true); rc |= dev_alloc(h, &blk_flags, (size_t)nblocks, true);
     rc |= dev_alloc(h, &part, max_items * kTN, true);
-    rc |= dev_alloc(h, &arrive, (size_t)nblocks, true); rc |= dev_alloc(h, &expected, (size_t)nblocks, true);
-    rc |= dev_alloc(h, &blk_slot, (size_t)nblocks, true); rc |= dev_alloc(h, &nbr_slots, (size_t)nblocks * 27, true);
     if (rc) {   // keep the old grid
         for (void* p : h->grid_allocs) (void)hipFree(p);
         h->grid_allocs.swap(old);
@@ -1736,14 +1599,12 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     S.inv_dx = (float)((double)n_grid / grid_lim);
     S.nbk = nbk;
     h->nblocks = nblocks;
-    S.gin = gin; S.gout = gout; S.gout_next = gout2; h->gout2 = gout2;
+    S.gin = gin; S.gout = gout;
     h->counts = counts; h->offsets = offsets; h->items = items; h->active_list = active_list; h->nbr_table = nbr_table;
     h->blk_items = blk_items; h->blk_flags = blk_flags; h->part = part;
-    h->arrive = arrive; h->expected = expected; h->blk_slot = blk_slot; h->nbr_slots = nbr_slots;
-    h->tail_ok = max_items * kTN * sizeof(float4) < ((size_t)1 << 31);   // byte offsets of the tail's buffer loads
     h->n_items = 0; h->n_active = 0;
     h->needs_sort = true; h->xref_valid = false;
-    h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false; h->grid_in_tail = false;
+    h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false;
     if (h->resort_auto) h->resort_interval = 4;
     return rc;
 }
@@ -1908,8 +1769,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gy") h->g[1] = (float)value;
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
-    else if (k == "profile") { h->profile = value != 0.0; h->profile_split = value == 2.0; }   // 2: block and grid kernels timed apart (no tail fusion)
-    else if (k == "fuse_grid") h->fuse_grid = value != 0.0;        // grid update in the tail of the block kernel (default on)
+    else if (k == "profile") h->profile = value != 0.0;
     else if (k == "scatter_bits") { PX_REQUIRE(value == 64 || value == 32, "scatter_bits must be 64 (exact) or 32 (packed pairs)"); h->scatter_bits = (int)value; }
     else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
     else if (k == "trace") h->trace = (int)value;
@@ -1931,7 +1791,6 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "grid_v_damping_scale") *value = h->damping;
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
-    else if (k == "fuse_grid") *value = tail_possible(h) ? 1.0 : 0.0;
     else if (k == "scatter_bits") *value = h->scatter_bits;
     else if (k == "n_active_blocks") *value = h->n_active;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
@@ -2011,17 +1870,14 @@ int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream) {
     if (n_substeps == 0) return 0;
     PX_REQUIRE(!h->dirty_grid, "pixie_mpm_step: a phase-API P2G is pending; finish the substep with phases 1,2 first");
     hipStream_t st = as_stream(stream);
-    // With the grid update in the tail of every P2G launch a run of n substeps is n + 1 launches: P2G(0)+grid(0),
-    // [G2P(i) + P2G(i+1) + grid(i+1)] x (n-1), G2P(n-1).  Otherwise the grid update is its own launch (2n + 1).
-    const bool tail = tail_possible(h);
     // substep 0: modifiers + stress + P2G at time t0
-    if (launch_particle(h, false, true, make_params(h, dt, h->time), st, tail)) return 1;
+    if (launch_particle(h, false, true, make_params(h, dt, h->time), st)) return 1;
     for (int i = 0; i < n_substeps; ++i) {
-        if (launch_grid(h, make_params(h, dt, h->time), dt, st)) return 1;   // (only the BC bookkeeping when the P2G launch did it)
+        if (launch_grid(h, make_params(h, dt, h->time), dt, st)) return 1;
         h->time = h->time + dt;  // mpm_solver_warp.py:637
         const bool last = (i == n_substeps - 1);
         // G2P of substep i fused with modifiers/stress/P2G of substep i+1 (evaluated at the new time)
-        if (launch_particle(h, true, !last, make_params(h, dt, h->time), st, tail)) return 1;
+        if (launch_particle(h, true, !last, make_params(h, dt, h->time), st)) return 1;
     }
     return 0;
 }

@@ -211,8 +211,9 @@ using namespace pixie;
 
 extern "C" int pixie_fill_densify(const float* d_pos, const float* d_opacity, const float* d_cov6, int n, int grid_n, double grid_dx,
                                   int32_t* d_grid_count, float* d_grid_density, void* stream) {
-    PX_REQUIRE(d_pos && d_opacity && d_cov6 && d_grid_count && d_grid_density && n >= 0 && grid_n > 0 && grid_dx > 0, "pixie_fill_densify: bad arguments");
-    if (n == 0) return 0;
+    PX_REQUIRE(n >= 0 && grid_n > 0 && grid_dx > 0, "pixie_fill_densify: bad arguments");
+    if (n == 0) return 0;      // (an empty device array has no address: checked before the pointers)
+    PX_REQUIRE(d_pos && d_opacity && d_cov6 && d_grid_count && d_grid_density, "pixie_fill_densify: null argument");
     FillGrid G{grid_n, (float)grid_dx, d_grid_count, d_grid_density};
     hipLaunchKernelGGL(densify_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, as_stream(stream), d_pos, d_opacity, d_cov6, n, G);
     PX_CHECK_HIP(hipGetLastError());
@@ -256,8 +257,9 @@ extern "C" int pixie_particle_volume(const float* d_pos, int n, int grid_n, doub
 }
 
 extern "C" int pixie_nearest_particle(const float* d_pos, int n, const float* d_new_pos, int n_new, int32_t* d_nearest, void* stream) {
-    PX_REQUIRE(d_pos && d_new_pos && d_nearest && n > 0 && n_new >= 0, "pixie_nearest_particle: bad arguments");
+    PX_REQUIRE(n > 0 && n_new >= 0, "pixie_nearest_particle: bad arguments");
     if (n_new == 0) return 0;
+    PX_REQUIRE(d_pos && d_new_pos && d_nearest, "pixie_nearest_particle: null argument");
     hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, as_stream(stream), d_pos, n, d_new_pos, n_new, d_nearest);
     PX_CHECK_HIP(hipGetLastError());
     return 0;

@@ -799,6 +799,10 @@ extern "C" int pixie_unet_forward(pixie_unet* h, const float* d_feat, const floa
                 return 0;
             }
         }
+        // Recording needs a capturable stream: refuse BEFORE doing the work, so that the call either succeeds completely or
+        // fails without having produced a result the caller would have to throw away.
+        if (h->use_graph && as_stream(stream) == nullptr)
+            fail("pixie_unet_forward: option \"graph\" needs a non-default stream (the legacy stream cannot be captured); pass a created stream or set graph = 0");
         refresh_bounds(h, stream);
         launch_all();               // eager: packs what needs packing, and IS this call's result
         if (h->use_graph) {

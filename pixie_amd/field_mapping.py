@@ -149,22 +149,20 @@ def map_pred_to_ply(pred_path: str, mask_path: str, grid_feature_path: str, outp
 
 
 def transform_nerf_to_world(ply_path: str, dataparser_path: str, world_output_path: str):
-    """map_pred_to_coords.py:77-120: undo nerfstudio's dataparser transform (world -> NeRF: scale * (T @ p)) on the PLY's
-    coordinates.  A 4x4 inverse and one (n,3) affine map on the host, float32 as in the reference."""
-    vertex, _ = read_ply(str(ply_path))
-    with open(dataparser_path, "r") as f:
-        dp_json = json.load(f)
-    scale = float(dp_json["scale"])
-    T = np.eye(4, dtype=np.float32)
-    T[:3, :] = np.asarray(dp_json["transform"], dtype=np.float32)
-    T_inv = np.linalg.inv(T)
-    coords_train = np.vstack((vertex["x"], vertex["y"], vertex["z"])).T.astype(np.float32)
-    coords_scaled = coords_train / scale
-    coords_h = np.concatenate([coords_scaled, np.ones((coords_scaled.shape[0], 1), dtype=np.float32)], axis=1)
-    coords_world = (T_inv @ coords_h.T).T[:, :3]
-    world = vertex.copy()
-    world["x"], world["y"], world["z"] = coords_world[:, 0], coords_world[:, 1], coords_world[:, 2]
-    write_ply(str(world_output_path), world, text=False)
+    """map_pred_to_coords.py:77-120: take the PLY's vertices from nerfstudio's training frame back to the world frame.
+    The dataparser maps world -> training as  q = s * (A p + t)  (its 3x4 `transform` is [A | t], `scale` is s), so the way
+    back is  p = A^-1 (q / s - t): a 3x3 inverse and one affine map over the (n, 3) vertex array, on the host."""
+    verts, _ = read_ply(str(ply_path))
+    with open(dataparser_path, "r") as fh:
+        parser = json.load(fh)
+    affine = np.asarray(parser["transform"], dtype=np.float64).reshape(3, 4)
+    lin_inv = np.linalg.inv(affine[:, :3])
+    q = np.stack([np.asarray(verts[ax], dtype=np.float64) for ax in ("x", "y", "z")], axis=1)
+    p = (q / float(parser["scale"]) - affine[:, 3]) @ lin_inv.T
+    moved = verts.copy()
+    for col, ax in enumerate(("x", "y", "z")):
+        moved[ax] = p[:, col].astype(np.float32)
+    write_ply(str(world_output_path), moved, text=False)
     logging.info(f"Saved WORLD-frame PLY to {world_output_path}")
 
 

@@ -5,8 +5,8 @@ Mirrors third_party/PhysGaussian/particle_filling/filling.py -- `fill_particles`
     -from particle_filling.filling import *
     +from pixie_amd.particle_filling import *
 and no Taichi.  The kernels are in csrc/particle_filling.hip; there is no CPU path.  Differences a caller can observe:
-the random offsets of new particles inside their cells come from a counter-based hash (reproducible; `seed=`) instead of
-ti.random(); `smooth=True` (mcubes.smooth, a host-side third-party routine) raises NotImplementedError; running out of
+the random offsets of new particles inside their cells come from a counter-based hash instead of ti.random() and the new
+particles are returned in a canonical order, so the whole output is reproducible for a given `seed=`; `smooth=True` (mcubes.smooth, a host-side third-party routine) raises NotImplementedError; running out of
 `max_samples` raises instead of writing past the buffer.
 """
 from __future__ import annotations
@@ -31,6 +31,20 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _canonical_order(new: torch.Tensor, n_dense: int) -> torch.Tensor:
+    """The kernels hand out output slots with one atomicAdd per cell, so the ORDER of the new particles depends on the
+    dispatch order (their positions do not: cell + counter-based hash).  Everything downstream indexes by particle id
+    (nearest-Gaussian attributes, volumes), so each phase's particles are put in lexicographic (x, y, z) order: the output
+    is reproducible row for row.  Dense-cell particles stay ahead of internal-fill ones, as in filling.py:355-375."""
+    def lexsort(t):
+        if t.shape[0] < 2:
+            return t
+        for axis in (2, 1, 0):
+            t = t[torch.sort(t[:, axis], stable=True).indices]
+        return t
+    return torch.cat([lexsort(new[:n_dense]), lexsort(new[n_dense:])], dim=0)
+
+
 def density_grids(pos, opacity, cov, grid_n: int, grid_dx: float):
     """densify_grids (:26-92): returns (count int32 (n,n,n), density float32 (n,n,n)) on the device."""
     dev = _dev(pos)
@@ -39,6 +53,8 @@ def density_grids(pos, opacity, cov, grid_n: int, grid_dx: float):
     cov = cov.detach().to(dev, torch.float32).reshape(-1, 6).contiguous()
     count = torch.zeros((grid_n,) * 3, dtype=torch.int32, device=dev)
     density = torch.zeros((grid_n,) * 3, dtype=torch.float32, device=dev)
+    if pos.shape[0] == 0:      # e.g. a boundary box that excludes every Gaussian: empty grids
+        return count, density
     check(_lib.load().pixie_fill_densify(_p(pos), _p(opacity), _p(cov), pos.shape[0], int(grid_n), float(grid_dx), _p(count), _p(density),
                                          _lib.current_stream_ptr()), "pixie_fill_densify")
     return count, density
@@ -83,7 +99,7 @@ def fill_particles(pos, opacity, cov, grid_n: int, max_samples: int, grid_dx: fl
     if fill_num > max_samples:
         raise RuntimeError(f"fill_particles: {fill_num} new particles do not fit max_samples = {max_samples} "
                            "(the reference would write past its buffer here)")
-    new = particles[:fill_num]
+    new = _canonical_order(particles[:fill_num], n_dense)
     if new_origin is not None:
         new = new + new_origin
     out = torch.cat([pos_clone, new], dim=0)
@@ -112,7 +128,9 @@ def init_filled_particles(pos, shs, cov, opacity, new_pos):
     p = pos.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
     q = new_pos.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
     nearest = torch.empty(q.shape[0], dtype=torch.int32, device=dev)
-    check(_lib.load().pixie_nearest_particle(_p(p), p.shape[0], _p(q), q.shape[0], _p(nearest), _lib.current_stream_ptr()), "pixie_nearest_particle")
+    if q.shape[0] > 0:         # nothing was filled: the attribute arrays come back unchanged
+        check(_lib.load().pixie_nearest_particle(_p(p), p.shape[0], _p(q), q.shape[0], _p(nearest), _lib.current_stream_ptr()),
+              "pixie_nearest_particle")
     idx = nearest.long()
     shs_tensor = torch.cat([shs2, shs2[idx]], dim=0)
     shs_tensor = shs_tensor.view(shs_tensor.shape[0], -1, 3)

@@ -403,15 +403,14 @@ class UNetRunner:
             return self._conv(cache, [x], b.prefix + ".conv", b.cout, 3, upsample=True, out_size=up_size)
         raise ValueError(b.kind)
 
-    def forward(self, feat: Optional[torch.Tensor], taps: Optional[dict] = None, proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """feat: (C_feat, D, H, W) -> (out_channels, D, H, W).  `proj0`: the output of projector.net[0] computed elsewhere
-        (pixie_projector_conv0 on the channels-last grid, shared with the other network); the pass then starts behind it."""
+    def _stem(self, feat: Optional[torch.Tensor], cache: dict, proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """FeatureProjector (diffusion_network.py:556-585) + input_blocks[0] (:762): the projector's last normalisation is
+        applied in the prologue of the first U-Net convolution, so its output is never materialised."""
         cfg, ops = self.cfg, self.ops
-        cache: dict = {}
         spatial = (proj0 if proj0 is not None else feat)[0].numel()
         x = feat
         pro_in, act_in, bound_in = None, ACT_NONE, 0.0
-        if cfg.has_projector:  # FeatureProjector.net, diffusion_network.py:556-585
+        if cfg.has_projector:
             q = "projector.net."
             if cfg.projector_hidden is None:
                 g = max(cfg.cond_dim // 2, 1)
@@ -429,23 +428,40 @@ class UNetRunner:
                 x = self._conv(cache, [x], q + "6", cfg.cond_dim, 1, pro=pro, act=ACT_SILU, bound=self._norm_bound(q + "4", spatial * (hid // 32)))
                 pro_in = ops.norm_finalize(self._sums(cache, x), spatial, 1, groups=32, weight=self.p[q + "7.weight"], bias=self.p[q + "7.bias"])
                 bound_in = self._norm_bound(q + "7", spatial * max(cfg.cond_dim // 32, 1))
+        first = self.plan.input_blocks[0][0]
+        return self._conv(cache, [x], first.prefix, first.cout, 3, pro=pro_in, act=act_in, bound=bound_in)
+
+    def _head(self, h: torch.Tensor, cache: dict) -> torch.Tensor:
+        """unet.out: LayerNorm -> LeakyReLU -> Conv3d (diffusion_network.py:869-873, :934)"""
+        pro = self.ops.norm_finalize(self._sums(cache, h), h[0].numel(), 0)
+        return self._conv(cache, [h], "unet.out.2", self.cfg.out_channels, 3, pro=pro, affine_key="unet.out.0", act=ACT_LEAKY,
+                          bound=self._norm_bound("unet.out.0", h[0].numel()))
+
+    def forward(self, feat: Optional[torch.Tensor], taps: Optional[dict] = None, proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat: (C_feat, D, H, W) -> (out_channels, D, H, W).  `proj0`: the output of projector.net[0] computed elsewhere
+        (pixie_projector_conv0 on the channels-last grid, shared with the other network); the pass then starts behind it.
+        `taps`, if a dict, receives the output of every block under the reference's module path (a dict that already holds
+        keys receives only those: large grids keep few tensors alive)."""
+        cache: dict = {}
+        only = set(taps) if taps else None
+
+        def tap(key, t):
+            if taps is not None and (only is None or key in only):
+                taps[key] = t
+
         plan = self.plan
         hs: List[torch.Tensor] = []
-        first = plan.input_blocks[0][0]
-        h = self._conv(cache, [x], first.prefix, first.cout, 3, pro=pro_in, act=act_in, bound=bound_in)
+        h = self._stem(feat, cache, proj0)
         hs.append(h)
-        if taps is not None:
-            taps["unet.input_blocks.0"] = h
+        tap("unet.input_blocks.0", h)
         for seq in plan.input_blocks[1:]:
             for b in seq:
                 h = self._block(b, [h], cache)
             hs.append(h)
-            if taps is not None:
-                taps[seq[0].prefix.rsplit(".", 1)[0]] = h
+            tap(seq[0].prefix.rsplit(".", 1)[0], h)
         for b in plan.middle:
             h = self._block(b, [h], cache)
-            if taps is not None:
-                taps[b.prefix] = h
+            tap(b.prefix, h)
         for seq in plan.output_blocks:
             skip = hs.pop()
             assert tuple(skip.shape[1:]) == tuple(h.shape[1:]), (skip.shape, h.shape)   # the up-conv already cropped
@@ -453,11 +469,8 @@ class UNetRunner:
             for b in seq:
                 h = self._block(b, parts, cache, up_size=tuple(hs[-1].shape[1:]) if (b.kind == "up" and hs) else None)
                 parts = [h]
-            if taps is not None:
-                taps[seq[0].prefix.rsplit(".", 1)[0]] = h
-        pro = ops.norm_finalize(self._sums(cache, h), h[0].numel(), 0)
-        return self._conv(cache, [h], "unet.out.2", cfg.out_channels, 3, pro=pro, affine_key="unet.out.0", act=ACT_LEAKY,
-                          bound=self._norm_bound("unet.out.0", h[0].numel()))
+            tap(seq[0].prefix.rsplit(".", 1)[0], h)
+        return self._head(h, cache)
 
 
 class UNetHandle:
@@ -553,7 +566,8 @@ class _PixieUNet(nn.Module):
         # replay a captured HIP graph per (shape, precision, parameter versions): the device runs the ~400 launches back to back
         # (128^3: 49.1 -> 45.5 ms per network) and the host queues ONE launch (16^3: 2.3 -> 0.7 ms).  PIXIE_UNET_GRAPH=0: eager.
         self.use_graph = os.environ.get("PIXIE_UNET_GRAPH", "1") == "1"
-        self._graphs: Dict[tuple, tuple] = {}
+        self._graphs: dict = {}
+        self._plist = None
 
     @staticmethod
     def _init(key, shape, shapes, gen) -> torch.Tensor:
@@ -608,21 +622,38 @@ class _PixieUNet(nn.Module):
             return self._handle.forward(x, proj0)
         return self._runner.forward(x, taps, proj0)
 
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): parameter storage may move
+        self._plist = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _param_list(self) -> List[torch.Tensor]:
+        """The parameters in registration order, cached: walking the module tree costs more than the rest of a 16^3 replay's
+        host work.  Parameter OBJECTS are stable (load_state_dict and .to() update them in place)."""
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = self._plist = list(self.parameters())
+        return pl
+
     def _forward_graphed(self, x: Optional[torch.Tensor], proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One sample through a captured HIP graph.  A forward pass is ~400 kernel launches; its launch sequence for a given
         (network, input shape, precision, parameter version) never changes, so it is captured once -- after one eager pass that
         packs the weights and takes the host-side parameter bounds -- and replayed with a single hipGraphLaunch: the device
-        runs the kernels back to back and the host queues one launch.  Returns a copy of the graph's static output."""
+        runs the kernels back to back and the host queues one launch.  The capture reads the CALLER's input tensor in place
+        (keyed by its address: a serving loop that refills one buffer, as bench.py and inference_combined.py's batch loop
+        do, never copies the 0.5 GB grid); a caller that brings a new address every call is switched, at its second address, to
+        a private input buffer the graph reads and each call copies into.  Returns a copy of the graph's static output."""
         src = proj0 if proj0 is not None else x
-        key = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index,
-               tuple((p.data_ptr(), p._version) for p in self.parameters()))   # storage AND version: `p.data = t` / `.to()` keep the version
+        base = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index,
+                tuple((p.data_ptr(), p._version) for p in self._param_list()))   # storage AND version: `p.data = t` / `.to()` keep the version
         run = (lambda t: self._forward_one(None, proj0=t)) if proj0 is not None else (lambda t: self._forward_one(t))
-        ent = self._graphs.get(key)
+        if self._graphs.get("base") != base:           # a new shape / parameter version invalidates every capture
+            self._graphs = {"base": base, "in_place": 0}
+        ent = self._graphs.get(src.data_ptr()) or self._graphs.get("copy")
         if ent is None:
-            self._graphs.clear()                       # a new shape / parameter version invalidates the old capture
             out = run(src)                             # eager warm-up: weight packing, bounds, function attributes
+            in_place = self._graphs["in_place"] < 1     # (each capture owns a workspace: 4 GB at 128^3, 30 GB at 256^3)
             try:
-                static_in = src.clone()
+                static_in = src if in_place else src.clone()
                 side = torch.cuda.Stream(src.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):          # capture must not run on the legacy default stream
@@ -637,9 +668,14 @@ class _PixieUNet(nn.Module):
                               RuntimeWarning)
                 self.use_graph = False
                 return out
-            ent = self._graphs[key] = (graph, static_in, static_out)
+            if in_place:
+                self._graphs["in_place"] += 1
+                ent = self._graphs[src.data_ptr()] = (graph, None, static_out)
+            else:
+                ent = self._graphs["copy"] = (graph, static_in, static_out)
         graph, static_in, static_out = ent
-        static_in.copy_(src)
+        if static_in is not None:
+            static_in.copy_(src)
         graph.replay()
         return static_out.clone()
 

@@ -685,6 +685,118 @@ def test_network_matches_reference_at_north_star_size(hip_device, D):
         torch.cuda.empty_cache()
 
 
+def test_network_256_cube_128_features(hip_device):
+    """BASELINE configs[4]'s per-GPU U-Net workload: 256^3 x 128 feature grid, hidden-128 projector (217 TFLOP per scene).
+    No CPU run of a whole network finishes at this size, so parity is held BLOCK BY BLOCK against the pinned oracle
+    ("tiles / sub-networks"): the exact-fp32 GPU pass records its block outputs (`taps`); each selected
+    block's recorded input goes (a) through the oracle's restatement of that block on the host cores and (b) through the
+    f16x3 kernels of the same block on the device; (a) vs the recorded fp32-path output and (a) vs (b) are both held to
+    1e-5.  Blocks: stem (projector 128 -> 128 -> 128 (3^3) -> 32 + input conv, all at 256^3), a full-resolution residual
+    block, the first down-sampling conv, a 128^3 residual block, the decoder block that up-samples back to 256^3, the last
+    decoder block (concatenated 128-channel input, folded 1x1x1 skip) and the head: every operator variant that runs at
+    256^3, where a 64-channel tensor is 4.3 GB (beyond 32-bit byte offsets).  Then both heads end to end, f16x3 against
+    exact fp32, with the timing of the f16x3 scene."""
+    import time
+    import psutil
+    from pixie_amd.unet import RegressionUNet, SegmentationUNet, predict_material_field
+    D, C = 256, 128
+    if psutil.virtual_memory().available < 96 * 2 ** 30:
+        pytest.skip(f"the block oracles at 256^3 need ~60 GB of host memory ({psutil.virtual_memory().available / 2 ** 30:.0f} GB free)")
+    kw = dict(feature_channels=C, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4), attention_resolutions=(), grid_size=D)
+    seg = SegmentationUNet(num_classes=8, **kw)
+    sd = synthetic_state_dict(seg.cfg, 0)
+    seg.load_numpy_state(sd)
+    seg = seg.to(hip_device).eval()
+    g = torch.Generator(device=hip_device).manual_seed(7)
+    feat = torch.randn((1, C, D, D, D), generator=g, device=hip_device).half().float()
+    zz = torch.arange(D, device=hip_device, dtype=torch.float32) - (D - 1) / 2
+    feat *= (zz[:, None, None] ** 2 + zz[None, :, None] ** 2 + zz[None, None, :] ** 2) < (0.35 * D) ** 2   # the voxeliser's occupancy ball
+
+    inputs, middle, outputs = unet_oracle.structure(seg.cfg)
+    blocks = {"unet.input_blocks.1": inputs[1], "unet.input_blocks.4": inputs[4], "unet.input_blocks.5": inputs[5],
+              "unet.output_blocks.11": outputs[11], "unet.output_blocks.15": outputs[15]}
+    # (module path of the block, paths whose recorded outputs are its inputs: previous block [, skip])
+    feeds = {"unet.input_blocks.1": ["unet.input_blocks.0"], "unet.input_blocks.4": ["unet.input_blocks.3"],
+             "unet.input_blocks.5": ["unet.input_blocks.4"], "unet.output_blocks.11": ["unet.output_blocks.10", "unet.input_blocks.4"],
+             "unet.output_blocks.15": ["unet.output_blocks.14", "unet.input_blocks.0"]}
+    want = {k: None for k in set(blocks) | {v for vs in feeds.values() for v in vs} | {"unet.input_blocks.0"}}
+    seg.conv_precision = "f32"
+    taps = dict(want)
+    t0 = time.perf_counter()
+    logits32 = seg(feat, taps)[0]
+    torch.cuda.synchronize()
+    print(f"256^3 x 128 exact-fp32 pass with taps: {time.perf_counter() - t0:.1f} s, {sum(t.numel() for t in taps.values()) * 4 / 2 ** 30:.1f} GiB of taps")
+    assert all(v is not None for v in taps.values()) and bool(torch.isfinite(logits32).all())
+    seg.conv_precision = "f16x3"
+    seg._prepare(hip_device)
+    runner16 = seg._runner
+    dt = torch.float32
+
+    def dev_rel_l2(got, ref):     # float64 on the device: the tensors are 4.3 GB each
+        r = ref.to(hip_device).double()
+        return float((got.double() - r).norm() / r.norm())
+
+    def check(name, ref, got32, got16):
+        e32, e16 = dev_rel_l2(got32, ref), dev_rel_l2(got16, ref)
+        print(f"  {name}: oracle block on the recorded input vs exact-fp32 kernels {e32:.2e}, vs f16x3 kernels {e16:.2e}")
+        assert e32 < 1e-5 and e16 < 1e-5, (name, e32, e16)
+
+    # stem: FeatureProjector + input_blocks[0]
+    t0 = time.perf_counter()
+    x = unet_oracle.projector_forward(sd, seg.cfg, feat.cpu(), dt)
+    ref = unet_oracle._block(sd, inputs[0][0], x, dt)[0]
+    del x
+    print(f"  (stem oracle: {time.perf_counter() - t0:.0f} s on {torch.get_num_threads()} host threads)")
+    check("stem (projector + input conv)", ref, taps["unet.input_blocks.0"], runner16._stem(feat[0], {}))
+    del ref
+    for key, seq in blocks.items():
+        t0 = time.perf_counter()
+        parts = [taps[k] for k in feeds[key]]
+        h = torch.cat([p.cpu() for p in parts], dim=0)[None]
+        for b in seq:
+            h = unet_oracle._block(sd, b, h, dt)
+        cache, parts16 = {}, list(parts)
+        for b in seq:
+            up = tuple(taps["unet.input_blocks.3"].shape[1:]) if b.kind == "up" else None
+            parts16 = [runner16._block(b, parts16, cache, up_size=up)]
+        print(f"  ({key} oracle: {time.perf_counter() - t0:.0f} s)")
+        check(key + " [" + "+".join(b.kind for b in seq) + f", {sum(int(p.shape[0]) for p in parts)} -> {seq[-1].cout} ch at {tuple(h.shape[2:])}]", h[0], taps[key], parts16[0])
+        del h, parts16
+    # head on the recorded last decoder output
+    hlast = taps["unet.output_blocks.15"]
+    hc = hlast.cpu()[None]
+    sp = hc.shape[-3:]
+    ref = F.conv3d(F.leaky_relu(F.layer_norm(hc, sp, torch.from_numpy(sd["unet.out.0.weight"]), torch.from_numpy(sd["unet.out.0.bias"]), 1e-5), unet_oracle.LEAKY),
+                   torch.from_numpy(sd["unet.out.2.weight"]), torch.from_numpy(sd["unet.out.2.bias"]), padding=1)[0]
+    check("head (LayerNorm + LeakyReLU + conv 64 -> 8)", ref, logits32, runner16._head(hlast, {}))
+    del ref, hc, taps, hlast
+    torch.cuda.empty_cache()
+
+    # both heads end to end: f16x3 vs exact fp32, the product's default executor (C handle + graph replay)
+    cont = RegressionUNet(out_channels=3, **kw)
+    cont.load_numpy_state(synthetic_state_dict(cont.cfg, 1000))
+    cont = cont.to(hip_device).eval()
+    res = {}
+    for prec in ("f16x3", "f32"):
+        seg.conv_precision = cont.conv_precision = prec
+        predict_material_field(seg, cont, feat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        combined, seg_pred, logits, cpred = predict_material_field(seg, cont, feat)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0)
+        assert bool(torch.isfinite(combined).all()) and bool((combined[0, 3:].sum(0) == 1).all())
+        res[prec] = (logits.clone(), cpred.clone(), seg_pred.clone())
+        print(f"  {prec}: 256^3 x 128 two-network forward {ms:.0f} ms = {D ** 3 / ms / 1e3:.1f} M voxels/s; peak device memory {torch.cuda.max_memory_allocated() / 2 ** 30:.0f} GiB")
+        del combined
+    assert dev_rel_l2(res["f32"][0][0], logits32) < 1e-6     # graph-replayed C executor == tapped Python walk
+    e_seg = float((res["f16x3"][0] - res["f32"][0]).norm() / res["f32"][0].norm())
+    e_cont = float((res["f16x3"][1] - res["f32"][1]).norm() / res["f32"][1].norm())
+    agree = float((res["f16x3"][2] == res["f32"][2]).float().mean())
+    print(f"  f16x3 vs exact fp32, whole networks: logits {e_seg:.2e}, regression {e_cont:.2e}, argmax agreement {agree:.6f}")
+    assert e_seg < 1e-4 and e_cont < 1e-4 and agree > 0.999
+
+
 @pytest.mark.parametrize("D", [16, 32])
 def test_graph_replay_is_bit_identical_to_eager(hip_device, D):
     """The captured HIP graph of a forward pass (pixie_amd.unet: use_graph) replays exactly the eager launch sequence:
@@ -704,7 +816,16 @@ def test_graph_replay_is_bit_identical_to_eager(hip_device, D):
     net.use_graph = True
     ga, gb, ga2 = net(xa).clone(), net(xb).clone(), net(xa).clone()
     assert torch.equal(ga, ea) and torch.equal(gb, eb) and torch.equal(ga2, ea)
-    assert len(net._graphs) == 1
+    # the first input address is captured in place (no copy of the grid per call), the second address switches to the graph
+    # that reads a private buffer: two captures, whatever the number of addresses after that
+    xc = xb.clone()
+    assert torch.equal(net(xc), eb) and torch.equal(net(xa), ea)
+    graphs = [k for k in net._graphs if k not in ("base", "in_place")]
+    assert sorted(map(str, graphs)) == sorted(["copy", str(xa.data_ptr())]), graphs
+    xa_saved = xa.clone()
+    xa.copy_(xb)                                   # refill the captured buffer: the replay reads the new content
+    assert torch.equal(net(xa), eb)
+    xa.copy_(xa_saved)
     torch.cuda.synchronize()
     t = {}
     for mode in (False, True):
@@ -721,7 +842,8 @@ def test_graph_replay_is_bit_identical_to_eager(hip_device, D):
         getattr(net.unet.out, "2").bias.add_(1.0)
     net.use_graph = True
     shifted = net(xa)
-    assert torch.allclose(shifted, ea + 1.0, atol=1e-5) and len(net._graphs) == 1
+    assert torch.allclose(shifted, ea + 1.0, atol=1e-5)
+    assert [k for k in net._graphs if k not in ("base", "in_place")] == [xa.data_ptr()]     # the old captures are gone
 
 
 @pytest.mark.parametrize("C,D", [(768, 12), (64, 16), (48, 9)])
