@@ -66,6 +66,7 @@ struct MpmPtrs {
     int* blk_flags;              // per block: bit 0 = active (particles nearby), bit 1 = slow-path particles wrote into gin here
     const int* active_list;      // the active blocks
     const int2* nbr_table;       // per active block (same order): [0] = (block id, 0), [1..27] = blk_items of its 27 neighbours
+    const unsigned* staged_lut;  // [256]: staged_index of tile nodes t (low half) and t + 256 (high half)
     unsigned long long* oob;     // [0] particles skipped because their stencil left the grid, [1] slow-path particles,
                                  // [2] slow-path particles dropped because they had left every active block
 };
@@ -501,6 +502,10 @@ __device__ __forceinline__ float scale_for(float bound, int top) {
     e = e > 120 ? 120 : (e < -80 ? -80 : e);
     return __uint_as_float((unsigned)(e + 127) << 23);
 }
+// 1 / s for s = 2^e, exactly, without a division (|e| <= 120: scale_for)
+__device__ __forceinline__ float pow2_reciprocal(float s) {
+    return __uint_as_float(0x7f000000u - __float_as_uint(s));
+}
 __device__ __forceinline__ unsigned long long to_fixed(float scaled) {
     return (unsigned long long)__double_as_longlong((double)scaled + kMagicD);
 }
@@ -673,9 +678,11 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             }
         });
     }
+    // where this thread's nodes go in the staged tile: fetched now, consumed behind the barrier
+    const unsigned lut = (nthr == kWG) ? S.staged_lut[tid] : 0u;
     __syncthreads();
     PX_MPM_STAMP(4);
-    const float iP = 1.0f / sP, iM = 1.0f / sM;
+    const float iP = pow2_reciprocal(sP), iM = pow2_reciprocal(sM);
     // ---- publish the tile: coalesced stores; the grid update sums the tiles that cover each node ----
     float4* dst = S.part + (size_t)blockIdx.x * kTN;
     if (!(TRACE && (sp.trace & 0x800)))
@@ -690,8 +697,10 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             } else {
                 o = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP), from_fixed(ta[3][idx], iM));
             }
-            float4* d = dst + staged_index(idx >> 6, (idx >> 3) & 7, idx & 7);
-            *d = o;
+            // (staged_index is ~30 instructions of selects per node; with the usual 256-thread work items each thread's two
+            // nodes are tid and tid + 256 and their staged positions come from a 1 KB table, two 16-bit halves of one word)
+            const int si = (nthr == kWG) ? (int)((idx < kWG) ? (lut & 0xffffu) : (lut >> 16)) : staged_index(idx >> 6, (idx >> 3) & 7, idx & 7);
+            dst[si] = o;
         }
     PX_MPM_STAMP(5);
     if (TRACE && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
@@ -1622,6 +1631,19 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     int rc = 0;
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
     rc |= dev_alloc(h, &S.oob, 3);
+    {
+        unsigned* lut = nullptr;
+        rc |= dev_alloc(h, &lut, (size_t)kWG);
+        if (!rc) {
+            unsigned host[kWG];
+            for (int t = 0; t < kWG; ++t) {
+                const int a = t, b = t + kWG;
+                host[t] = (unsigned)staged_index(a >> 6, (a >> 3) & 7, a & 7) | ((unsigned)staged_index(b >> 6, (b >> 3) & 7, b & 7) << 16);
+            }
+            if (hipMemcpy(lut, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+        }
+        S.staged_lut = lut;
+    }
     rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n); rc |= dev_alloc(h, &h->order2, n);
     rc |= dev_alloc(h, &h->d_n_items, 4);
     rc |= alloc_grid(h, n_grid, grid_lim);

@@ -193,15 +193,22 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
 }
 
 // Rotation factor R of the polar decomposition F = R S by the scaled Newton iteration
-// R <- (g R + R^-T / g) / 2 (two Frobenius-scaled steps, then four plain ones): a third of the instructions and of
+// R <- (g R + R^-T / g) / 2 (two Frobenius-scaled steps, then plain ones): a third of the instructions and of
 // the dependency chain of svd3.  For det F > 0 it equals U V^T of the reference's wp.svd3 to fp32 roundoff, which is
 // all kirchoff_stress_FCR (mpm_utils.py:10-17) needs.  Returns false when the iteration has not settled (extreme
 // conditioning) or det F <= 0 (inverted element, where U V^T of the proper-rotation SVD is NOT the polar factor);
 // the caller then takes the svd3 route.
+//
+// Stopping rule.  After ONE step every singular value of the iterate is >= 1 ((g s + 1/(g s))/2 >= 1), so from then on
+// |R|_F^2 - 3 = sum (s_i^2 - 1) >= 2 max_i (s_i - 1): the Frobenius norm -- nine FMAs -- bounds the distance to the rotation.
+// A step entered with max (s_i - 1) = e leaves e^2 / 2: an iterate with |R|_F^2 - 3 < 4e-4 (e < 2e-4) needs exactly one more
+// step (2e-8, below fp32 roundoff), and that step is the lane's last.  A lane stops at ITS OWN last step (the iterate is
+// frozen afterwards), so its result does not depend on which other particles share its wave; the wave leaves the loop once
+// every lane has stopped -- after 2 of the 6 steps for strains below ~1.5 %, after 3 for the strains of a stable simulation.
 PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
     R = F;
     float det = 1.0f;
-    bool settled = false;   // this lane's iterate moved by < 2e-6 in its last step: frozen from then on
+    bool settled = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -219,28 +226,27 @@ PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
         const float d = R.m[0] * cof.m[0] + R.m[1] * cof.m[1] + R.m[2] * cof.m[2];
         if (it == 0) det = d;
         const float inv_d = px_rcp(d);
+        float nr = 0.0f;
+        for (int i = 0; i < 9; ++i) nr += R.m[i] * R.m[i];
+        // the entering iterate is within 2e-4 of a rotation (valid from the second step on; NaN never is): last step
+        const bool last = (it >= 1) && (nr - 3.0f < 4.0e-4f) && (nr - 3.0f > -1.0e-5f);
         float a = 0.5f, b = 0.5f * inv_d;  // R <- a R + b cof
         if (it < 2) {
-            float nr = 0.0f, nc = 0.0f;
-            for (int i = 0; i < 9; ++i) { nr += R.m[i] * R.m[i]; nc += cof.m[i] * cof.m[i]; }
+            float nc = 0.0f;
+            for (int i = 0; i < 9; ++i) nc += cof.m[i] * cof.m[i];
             // g^2 = |R^-T|_F / |R|_F = |cof|_F / (|d| |R|_F)   (only steers the convergence: approximate is fine)
             const float g2 = px_sqrt(nc * px_rcp(nr)) * fabsf(inv_d);
             const float g = px_sqrt(g2);
             a = 0.5f * g;
             b = 0.5f * inv_d * px_rcp(g);
         }
-        float delta = 0.0f;
         for (int i = 0; i < 9; ++i) {
             const float r = a * R.m[i] + b * cof.m[i];
-            delta = fmaxf(delta, fabsf(r - R.m[i]));
             if (!settled) R.m[i] = r;
         }
-        // A lane stops at ITS OWN convergence (the Newton step that moved it by < 2e-6 leaves an error of ~1e-12), so
-        // its result does not depend on which other particles share its wave; the wave leaves the loop once every
-        // lane has settled -- typically after 3 of the 6 steps for the strains of a stable simulation.
-        if (!settled && delta < 2e-6f) settled = true;   // NaN (singular F) never settles
+        if (last) settled = true;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (it >= 2 && __all(settled)) break;
+        if (it >= 1 && __all(settled)) break;
 #endif
     }
     return det > 0.0f && settled;
