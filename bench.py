@@ -98,6 +98,9 @@ def parse():
                     help="also time one scene's launches with the two networks on two HIP streams (roofline.avg_launch_ms_dual_stream)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
                     help="torch.distributed backend for --gpus N > 1 (default nccl = RCCL over xGMI; gloo only for --launcher-selftest)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="the whole N-rank bench path -- self-launch, rendezvous, per-rank set-up, the timing protocol of every leg, the field "
+                         "all-gather, the JSON assembly -- on CPU tensors with gloo and no kernels (what an 8-GPU run does around its kernels)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only check of the multi-process path (self-launch, rendezvous, barrier, max-over-ranks timing, "
                          "field all-gather) on a tiny synthetic field; runs no kernel and reports no throughput")
@@ -108,10 +111,50 @@ def parse():
 
 
 def barrier_sync(world):
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, n_steps, world, device):
+    """The timing protocol of every leg: barrier + device sync, n_steps steps, barrier + device sync, MAX over ranks."""
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    barrier_sync(world)
+    return max_over_ranks(time.perf_counter() - t0, world, device)
+
+
+def time_allgather(cont_pred, seg_pred, world, device, reps=5):
+    """The collective alone (ms per all-gather of one step's fields, max over ranks): lets a 1 -> 8 GPU curve be split into
+    compute and exchange.  None on one rank."""
+    if world == 1:
+        return None
+    pd.all_gather_fields(cont_pred, seg_pred)
+    return 1e3 * timed_steps(lambda: pd.all_gather_fields(cont_pred, seg_pred), reps, world, device) / reps
+
+
+def pin_rank_resources(rank, world):
+    """N ranks on one host: give each its share of the cores (torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset,
+    which would make the CPU-side set-up of every rank single-threaded) and keep the ranks off each other's cores."""
+    cores = os.cpu_count() or 1
+    if world <= 1:
+        return cores
+    share = max(1, cores // world)
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        mine = avail[rank * len(avail) // world:(rank + 1) * len(avail) // world]
+        if mine:
+            os.sched_setaffinity(0, mine)
+            share = len(mine)
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(share)
+    return share
 
 
 def max_over_ranks(seconds: float, world: int, device) -> float:
@@ -207,14 +250,19 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     for _ in range(n_warm):
         step()
     executor = f"{seg.executor}{'+hip_graph' if seg.use_graph else ''}"
-    barrier_sync(world)
     tele0 = gpu_telemetry(device.index or 0)
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
+    tele_mid = {}
+
+    def step_and_sample(_n=[0]):
         step()
-    tele_mid = gpu_telemetry(device.index or 0)    # while the last steps are still running on the device
-    barrier_sync(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world, device)
+        _n[0] += 1
+        if _n[0] == n_steps:
+            tele_mid.update(gpu_telemetry(device.index or 0))    # while the last steps are still running on the device
+    dt = timed_steps(step_and_sample, n_steps, world, device)
+    ag_ms = None
+    if world > 1:
+        _, sp_, _, cp_ = predict_material_field(seg, cont, feat)
+        ag_ms = time_allgather(cp_, sp_, world, device)
     # where a step's time goes: events around each network's forward (one graph replay + the copy of its output) and the
     # combine, three more scenes right after the timed region
     parts = {"seg_forward_ms": 0.0, "cont_forward_ms": 0.0, "combine_and_stack_ms": 0.0}
@@ -290,7 +338,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     conv_ms = sum(v[0] for v in agg.values()) / 2.0
     return dict(seconds=dt, steps=n_steps, voxels=world * n_steps * D ** 3, flops_scene=flops_scene, roofline=roof, precision=precision, executor=executor,
                 conv_ms_per_step=conv_ms, layer_ms={str(k): round(v[0] / 2.0, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
-                kernel_avg=prof.by_variant(), kernel_avg_timed=kernel_avg_timed, step_parts=parts)
+                kernel_avg=prof.by_variant(), kernel_avg_timed=kernel_avg_timed, step_parts=parts, allgather_ms=ag_ms)
 
 
 def bench_shipped_shape(args, device):
@@ -581,6 +629,109 @@ def launcher_selftest(args, rank, world):
     return 0 if ok else 1
 
 
+def bench_unet_dry(args, rank, world, device, **_):
+    """--dry-run stand-in for bench_unet: the same control flow (per-rank set-up, set-up passes, warm-up, the timing protocol,
+    the field all-gather in its wire format, max over ranks) on CPU tensors of a small grid; no kernel runs."""
+    D = min(args.grid, 16)
+    cfgs = [UNetConfig(feature_channels=args.feature_channels, grid_size=D, out_channels=oc) for oc in (8, 3)]
+    feat = torch.from_numpy(feature_grid(D, args.feature_channels, seed=100 + rank))
+    gen = torch.Generator().manual_seed(rank)
+    cont_pred = torch.randn((1, 3, D, D, D), generator=gen)
+    seg_pred = torch.randint(0, 8, (1, D, D, D), generator=gen, dtype=torch.int32)
+
+    def step():
+        time.sleep(1e-3)     # (the device work of a scene)
+        if world > 1:
+            pd.all_gather_fields(cont_pred, seg_pred)
+    for _ in range(3 + args.warmup):
+        step()
+    dt = timed_steps(step, args.steps, world, device)
+    return dict(seconds=dt, steps=args.steps, voxels=world * args.steps * D ** 3, flops_scene=sum(conv_flops(c) for c in cfgs), roofline=None,
+                precision="f16x3", executor="dry-run", conv_ms_per_step=0.0, layer_ms={}, kernel_avg={}, kernel_avg_timed=None,
+                step_parts={"note": f"dry run on a {D}^3 grid of CPU tensors", "feature_grid_sum": float(feat.sum())},
+                allgather_ms=time_allgather(cont_pred, seg_pred, world, device))
+
+
+def bench_mpm_dry(args, rank, world, device, particles, n_grid, substeps, tag, **_):
+    """--dry-run stand-in for bench_mpm: per-rank scene generation (the CPU-side cost every rank pays concurrently) and the
+    timing protocol; no kernel runs."""
+    sc = mpm_ball_scene(min(particles, 20000), seed=rank, n_grid=n_grid)
+    dt = timed_steps(lambda: time.sleep(1e-5), 10, world, device)
+    return {"value": world * sc["x"].shape[0] * 10 / dt, "unit": "particle-steps/s", "substeps": 10, "us_per_substep": 1e5 * dt,
+            "config": {"workload": f"dry run: {sc['x'].shape[0]} particles generated per rank, no kernels", "scatter_bits": 64},
+            "algorithmic_GBps": None, "frac_of_hbm_roofline_per_gpu": None, "roofline": None, "finite": True, "out_of_bounds": 0,
+            "rebins": 0, "slow_path_particle_substeps": 0}
+
+
+def assemble_line(args, world, u, u32=None, m=None, m_large=None, m_alt=None, m_large_alt=None, m_multi=None, ft=None, shipped=None,
+                  u256=None, cpu=None, threads_per_rank=None, dry=False):
+    """The ONE JSON line rank 0 prints, from the legs' records (shared by the real run and --dry-run)."""
+    vps = u["voxels"] / u["seconds"]
+    ms_step = 1e3 * u["seconds"] / u["steps"]
+    line = {
+        "metric": "voxels/s (128^3 U-Net fwd) + MPM particle-steps/s",
+        "value": vps, "unit": "voxels/s", "n_gpus": world, "world": world,
+        "collective_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+        "backend": (torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else "")) if world > 1 else None,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if u["precision"] == "f32" else "f32 (operands split fp16 hi+lo, 3 f16 MFMAs/product, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.grid}^3x{args.feature_channels} feature grid -> SegmentationUNet+RegressionUNet forward "
+                               f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
+                   "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
+                   "weights": "seeded random init of the reference architecture",
+                   "executor": u["executor"] + " (one pixie_unet_forward call per network; graph replays of >= 128^3 grids run back to back on one stream)"},
+        "unet_tflops": u["flops_scene"] * world * u["steps"] / u["seconds"] / 1e12,
+        "unet_conv_ms_per_step": u["conv_ms_per_step"],
+        "step_decomposition": u["step_parts"],
+        # N > 1: the collective timed alone, so that the driver's 1 -> 8 curve splits into compute and exchange
+        "allgather_ms": u.get("allgather_ms"),
+        "compute_ms_per_step": (ms_step - u["allgather_ms"]) if u.get("allgather_ms") is not None else ms_step,
+        "host_threads_per_rank": threads_per_rank,
+        "roofline": u["roofline"],
+    }
+    if dry:
+        line["dry_run"] = True
+        line["metric"] = "DRY RUN (CPU tensors, no kernels): " + line["metric"]
+    if u32 is not None:
+        line["exact_f32"] = {"dtype": "f32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32)", "value": u32["voxels"] / u32["seconds"], "unit": "voxels/s",
+                             "steps": u32["steps"], "ms_per_step": 1e3 * u32["seconds"] / u32["steps"],
+                             "unet_tflops": u32["flops_scene"] * world * u32["steps"] / u32["seconds"] / 1e12, "roofline": u32["roofline"]}
+    if m is not None:
+        line["mpm"] = m
+        if m_alt is not None:
+            line["mpm"]["other_scatter_mode"] = {k: m_alt[k] for k in ("value", "us_per_substep", "config", "frac_of_hbm_roofline_per_gpu", "roofline", "finite")}
+        if m_multi is not None:
+            line["mpm"]["multi_scene"] = m_multi
+    if m_large is not None:
+        line["mpm_1m"] = m_large
+        if m_large_alt is not None:
+            line["mpm_1m"]["other_scatter_mode"] = {k: m_large_alt[k] for k in ("value", "substeps", "us_per_substep", "config", "frac_of_hbm_roofline_per_gpu", "roofline", "finite")}
+    if ft is not None:
+        line["field_to_particles"] = ft
+    if shipped is not None:
+        line["shipped_shape_64x768"] = shipped
+    if u256 is not None:
+        line["unet_256x128"] = {"workload": "256^3 x 128 feature grid -> SegmentationUNet+RegressionUNet forward (+combine), 1 scene per step (BASELINE configs[4] per-GPU grid)",
+                                "value": u256["voxels"] / u256["seconds"], "unit": "voxels/s", "steps": u256["steps"],
+                                "ms_per_step": 1e3 * u256["seconds"] / u256["steps"],
+                                "unet_tflops": u256["flops_scene"] * u256["steps"] / u256["seconds"] / 1e12, "roofline": u256["roofline"],
+                                "step_decomposition": u256["step_parts"], "peak_device_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    if cpu is not None:
+        line["cpu_baseline"] = cpu["unet"]
+        if "mpm" in line:
+            line["mpm"]["cpu_baseline"] = cpu["mpm"]
+        if "mpm_1m" in line and "mpm_1m" in cpu:
+            line["mpm_1m"]["cpu_baseline"] = cpu["mpm_1m"]
+    line["layer_ms_top"] = u["layer_ms"]
+    # per kernel NAME, all shapes pooled: comparable with the avg column of profiles/*_kernel_stats.csv (rocprofv3 --stats)
+    line["conv_kernel_avg_ms"] = u["kernel_avg"]                           # single-stream pass
+    if u["kernel_avg_timed"] is not None:
+        line["conv_kernel_avg_ms_dual_stream"] = u["kernel_avg_timed"]    # two streams: launches of the two networks overlap
+    return line
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -588,28 +739,35 @@ def main():
     if args.launcher_selftest:
         rank, world, local = pd.init_process_group(args.backend or "gloo")
         raise SystemExit(launcher_selftest(args, rank, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (pixie_amd has no CPU path)")
-    rank, world, local = pd.init_process_group(args.backend)
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (pixie_amd has no CPU path); --dry-run exercises the N-rank control path on CPU tensors")
+    rank, world, local = pd.init_process_group((args.backend or "gloo") if dry else args.backend)
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    threads = pin_rank_resources(rank, world)
+    if dry:
+        device = torch.device("cpu")
+        U, M = bench_unet_dry, bench_mpm_dry
+    else:
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        U, M = bench_unet, bench_mpm
 
     # stdout carries exactly ONE line (the JSON); the solver shim's reference-style progress prints go to stderr
     with contextlib.redirect_stdout(sys.stderr):
-        u = bench_unet(args, rank, world, device)
+        u = U(args, rank, world, device)
         # the same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32, no operand splitting): the precision ruling
         # of VERDICT r1 asks for this line beside the headline; a few steps suffice (bounded run time)
         u32 = None
         if not args.no_exact_f32 and u["precision"] == "f16x3":
-            u32 = bench_unet(args, rank, world, device, precision_override="f32", steps=min(args.steps, 3), warmup=1)
-        m = None if args.no_mpm else bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k", loop_api=True)
+            u32 = U(args, rank, world, device, precision_override="f32", steps=min(args.steps, 3), warmup=1)
+        m = None if args.no_mpm else M(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k", loop_api=True)
         # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120, 2000 substeps): where the HBM roofline fraction is meaningful
-        m_large = None if (args.no_mpm or args.no_mpm_large) else bench_mpm(args, rank, world, device, 1_000_000, 120, args.mpm_large_substeps, "1m")
+        m_large = None if (args.no_mpm or args.no_mpm_large) else M(args, rank, world, device, 1_000_000, 120, args.mpm_large_substeps, "1m")
         other_bits = {64: 32, 32: 64}
-        m_alt = m_large_alt = m_multi = None
-        if rank == 0 and world == 1 and not args.no_mpm:
+        m_alt = m_large_alt = m_multi = ft = shipped = u256 = cpu = None
+        if rank == 0 and world == 1 and not args.no_mpm and not dry:
             # the other scatter mode beside the default (exact 64-bit <-> packed 32-bit pairs), and the multi-scene leg
             m_alt = bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k",
                               scatter_bits=other_bits[m["config"]["scatter_bits"]])
@@ -617,76 +775,21 @@ def main():
                 m_large_alt = bench_mpm(args, rank, world, device, 1_000_000, 120, min(args.mpm_large_substeps, 500), "1m",
                                         scatter_bits=other_bits[m_large["config"]["scatter_bits"]])
             m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
-        ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
-        shipped = bench_shipped_shape(args, device) if (rank == 0 and world == 1 and not args.no_shipped_shape) else None
-        # BASELINE configs[4]'s per-GPU U-Net workload: 256^3 x 128 (217 TFLOP per scene, ~60 GiB of workspace)
-        u256 = None
-        if rank == 0 and world == 1 and not args.no_unet_256 and u["precision"] == "f16x3" and args.grid == 128:
-            torch.cuda.empty_cache()
-            big = argparse.Namespace(**{**vars(args), "grid": 256, "feature_channels": 128, "dual_stream_diagnostic": False})
-            u256 = bench_unet(big, rank, world, device, steps=2, warmup=0, device_input=True)
-            torch.cuda.empty_cache()
-        cpu = None
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baselines(args)
+        if not dry:
+            ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
+            shipped = bench_shipped_shape(args, device) if (rank == 0 and world == 1 and not args.no_shipped_shape) else None
+            # BASELINE configs[4]'s per-GPU U-Net workload: 256^3 x 128 (217 TFLOP per scene, ~60 GiB of workspace)
+            if rank == 0 and world == 1 and not args.no_unet_256 and u["precision"] == "f16x3" and args.grid == 128:
+                torch.cuda.empty_cache()
+                big = argparse.Namespace(**{**vars(args), "grid": 256, "feature_channels": 128, "dual_stream_diagnostic": False})
+                u256 = bench_unet(big, rank, world, device, steps=2, warmup=0, device_input=True)
+                torch.cuda.empty_cache()
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                cpu = cpu_baselines(args)
 
     if rank == 0:
-        vps = u["voxels"] / u["seconds"]
-        line = {
-            "metric": "voxels/s (128^3 U-Net fwd) + MPM particle-steps/s",
-            "value": vps, "unit": "voxels/s", "n_gpus": world, "world": world,
-            "collective_ranks": torch.distributed.get_world_size() if world > 1 else 1,
-            "backend": (torch.distributed.get_backend() + " (RCCL)") if world > 1 else None,
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * u["seconds"] / u["steps"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if u["precision"] == "f32" else "f32 (operands split fp16 hi+lo, 3 f16 MFMAs/product, fp32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": f"{args.grid}^3x{args.feature_channels} feature grid -> SegmentationUNet+RegressionUNet forward "
-                                   f"(+argmax/one-hot combine" + (", + all-gather of fields" if world > 1 else "") + "), 1 scene per GPU per step",
-                       "grid": args.grid, "feature_channels": args.feature_channels, "parallelism": f"scene-parallel x{world}",
-                       "weights": "seeded random init of the reference architecture",
-                       "executor": u["executor"] + " (one pixie_unet_forward call per network; graph replays of >= 128^3 grids run back to back on one stream)"},
-            "unet_tflops": u["flops_scene"] * world * u["steps"] / u["seconds"] / 1e12,
-            "unet_conv_ms_per_step": u["conv_ms_per_step"],
-            "step_decomposition": u["step_parts"],
-            "roofline": u["roofline"],
-        }
-        if u32 is not None:
-            line["exact_f32"] = {"dtype": "f32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32)", "value": u32["voxels"] / u32["seconds"], "unit": "voxels/s",
-                                 "steps": u32["steps"], "ms_per_step": 1e3 * u32["seconds"] / u32["steps"],
-                                 "unet_tflops": u32["flops_scene"] * world * u32["steps"] / u32["seconds"] / 1e12, "roofline": u32["roofline"]}
-        if m is not None:
-            line["mpm"] = m
-            if m_alt is not None:
-                line["mpm"]["other_scatter_mode"] = {k: m_alt[k] for k in ("value", "us_per_substep", "config", "frac_of_hbm_roofline_per_gpu", "roofline", "finite")}
-            if m_multi is not None:
-                line["mpm"]["multi_scene"] = m_multi
-        if m_large is not None:
-            line["mpm_1m"] = m_large
-            if m_large_alt is not None:
-                line["mpm_1m"]["other_scatter_mode"] = {k: m_large_alt[k] for k in ("value", "substeps", "us_per_substep", "config", "frac_of_hbm_roofline_per_gpu", "roofline", "finite")}
-        if ft is not None:
-            line["field_to_particles"] = ft
-        if shipped is not None:
-            line["shipped_shape_64x768"] = shipped
-        if u256 is not None:
-            line["unet_256x128"] = {"workload": "256^3 x 128 feature grid -> SegmentationUNet+RegressionUNet forward (+combine), 1 scene per step (BASELINE configs[4] per-GPU grid)",
-                                    "value": u256["voxels"] / u256["seconds"], "unit": "voxels/s", "steps": u256["steps"],
-                                    "ms_per_step": 1e3 * u256["seconds"] / u256["steps"],
-                                    "unet_tflops": u256["flops_scene"] * u256["steps"] / u256["seconds"] / 1e12, "roofline": u256["roofline"],
-                                    "step_decomposition": u256["step_parts"], "peak_device_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
-        if cpu is not None:
-            line["cpu_baseline"] = cpu["unet"]
-            if "mpm" in line:
-                line["mpm"]["cpu_baseline"] = cpu["mpm"]
-            if "mpm_1m" in line and "mpm_1m" in cpu:
-                line["mpm_1m"]["cpu_baseline"] = cpu["mpm_1m"]
-        line["layer_ms_top"] = u["layer_ms"]
-        # per kernel NAME, all shapes pooled: comparable with the avg column of profiles/*_kernel_stats.csv (rocprofv3 --stats)
-        line["conv_kernel_avg_ms"] = u["kernel_avg"]                           # single-stream pass
-        if u["kernel_avg_timed"] is not None:
-            line["conv_kernel_avg_ms_dual_stream"] = u["kernel_avg_timed"]    # two streams: launches of the two networks overlap
-        print(json.dumps(line))
+        print(json.dumps(assemble_line(args, world, u, u32, m, m_large, m_alt, m_large_alt, m_multi, ft, shipped, u256, cpu,
+                                       threads_per_rank=threads, dry=dry)))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

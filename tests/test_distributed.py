@@ -82,6 +82,31 @@ def test_bench_self_launch_gloo_world2():
     assert rec["n_gpus"] == 2 and rec["world"] == 2 and rec["collective_ranks"] == 2 and rec["backend"] == "gloo" and rec["gather_ok"]
 
 
+def test_bench_dry_run_gloo_world2():
+    """`python bench.py --gpus 2 --dry-run`: everything an N-GPU bench run does AROUND its kernels -- self-launch, rendezvous,
+    per-rank core pinning and synthetic set-up, the timing protocol of the U-Net and both MPM legs, the all-gather timed on its
+    own, and the assembly of the full JSON line by the same code as the real run -- on CPU tensors (the first
+    8-GPU run must not die in code the CPU suite never executed)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["collective_ranks"] == 2 and rec["backend"] == "gloo"
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "allgather_ms", "compute_ms_per_step", "host_threads_per_rank", "mpm", "mpm_1m", "exact_f32"):
+        assert key in rec, key
+    assert rec["allgather_ms"] > 0 and rec["compute_ms_per_step"] < rec["ms_per_step"]
+    assert rec["scaling"] == "weak" and rec["config"]["parallelism"] == "scene-parallel x2"
+    assert rec["host_threads_per_rank"] >= 1
+
+
 @pytest.mark.gpu
 def test_rccl_process_group_and_graph_capture_coexist(hip_device):
     """A live RCCL process group (communicator, watchdog thread) while the U-Net forward is captured into HIP graphs and
