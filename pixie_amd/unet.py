@@ -640,18 +640,24 @@ class _PixieUNet(nn.Module):
         packs the weights and takes the host-side parameter bounds -- and replayed with a single hipGraphLaunch: the device
         runs the kernels back to back and the host queues one launch.  The capture reads the CALLER's input tensor in place
         (keyed by its address: a serving loop that refills one buffer, as bench.py and inference_combined.py's batch loop
-        do, never copies the 0.5 GB grid); a caller that brings a new address every call is switched, at its second address, to
-        a private input buffer the graph reads and each call copies into.  Returns a copy of the graph's static output."""
+        do, never copies the 0.5 GB grid); a caller that brings a new address every call gets a graph that reads a private input
+        buffer each call copies into.  Which of the two is decided at the SECOND call (the first runs eagerly), so nobody pays
+        for two captures.  Returns a copy of the graph's static output."""
         src = proj0 if proj0 is not None else x
         base = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index,
                 tuple((p.data_ptr(), p._version) for p in self._param_list()))   # storage AND version: `p.data = t` / `.to()` keep the version
         run = (lambda t: self._forward_one(None, proj0=t)) if proj0 is not None else (lambda t: self._forward_one(t))
         if self._graphs.get("base") != base:           # a new shape / parameter version invalidates every capture
-            self._graphs = {"base": base, "in_place": 0}
+            self._graphs = {"base": base, "first_ptr": None}
         ent = self._graphs.get(src.data_ptr()) or self._graphs.get("copy")
         if ent is None:
-            out = run(src)                             # eager warm-up: weight packing, bounds, function attributes
-            in_place = self._graphs["in_place"] < 1     # (each capture owns a workspace: 4 GB at 128^3, 30 GB at 256^3)
+            out = run(src)                             # eager: weight packing, bounds, function attributes -- and this call's result
+            if self._graphs["first_ptr"] is None:      # first call: remember the address, capture when it is known whether it comes back
+                self._graphs["first_ptr"] = src.data_ptr()
+                return out
+            # second call: the same buffer again -> capture in place; another one -> capture on a private input buffer, for
+            # good (at most two captures; each owns a workspace: 4 GB at 128^3, 30 GB at 256^3)
+            in_place = self._graphs["first_ptr"] == src.data_ptr() and "copy" not in self._graphs
             try:
                 static_in = src if in_place else src.clone()
                 side = torch.cuda.Stream(src.device)
@@ -669,7 +675,6 @@ class _PixieUNet(nn.Module):
                 self.use_graph = False
                 return out
             if in_place:
-                self._graphs["in_place"] += 1
                 ent = self._graphs[src.data_ptr()] = (graph, None, static_out)
             else:
                 ent = self._graphs["copy"] = (graph, static_in, static_out)

@@ -814,13 +814,13 @@ def test_graph_replay_is_bit_identical_to_eager(hip_device, D):
     net.use_graph = False
     ea, eb = net(xa).clone(), net(xb).clone()
     net.use_graph = True
-    ga, gb, ga2 = net(xa).clone(), net(xb).clone(), net(xa).clone()
+    # first call: eager, the address is remembered; second call with the SAME buffer: captured in place (no copy of the grid
+    # per call); any other address: the graph that reads a private buffer -- two captures at most
+    ga, ga2, gb = net(xa).clone(), net(xa).clone(), net(xb).clone()
     assert torch.equal(ga, ea) and torch.equal(gb, eb) and torch.equal(ga2, ea)
-    # the first input address is captured in place (no copy of the grid per call), the second address switches to the graph
-    # that reads a private buffer: two captures, whatever the number of addresses after that
     xc = xb.clone()
     assert torch.equal(net(xc), eb) and torch.equal(net(xa), ea)
-    graphs = [k for k in net._graphs if k not in ("base", "in_place")]
+    graphs = [k for k in net._graphs if k not in ("base", "first_ptr")]
     assert sorted(map(str, graphs)) == sorted(["copy", str(xa.data_ptr())]), graphs
     xa_saved = xa.clone()
     xa.copy_(xb)                                   # refill the captured buffer: the replay reads the new content
@@ -841,9 +841,9 @@ def test_graph_replay_is_bit_identical_to_eager(hip_device, D):
     with torch.no_grad():
         getattr(net.unet.out, "2").bias.add_(1.0)
     net.use_graph = True
-    shifted = net(xa)
-    assert torch.allclose(shifted, ea + 1.0, atol=1e-5)
-    assert [k for k in net._graphs if k not in ("base", "in_place")] == [xa.data_ptr()]     # the old captures are gone
+    shifted, shifted2 = net(xa).clone(), net(xa).clone()
+    assert torch.allclose(shifted, ea + 1.0, atol=1e-5) and torch.equal(shifted, shifted2)
+    assert [k for k in net._graphs if k not in ("base", "first_ptr")] == [xa.data_ptr()]     # the old captures are gone
 
 
 @pytest.mark.parametrize("C,D", [(768, 12), (64, 16), (48, 9)])
