@@ -484,12 +484,13 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
 // order-independent.
 // PACKED mode (F_PACK32, set_scalar "scatter_bits" 32): two 32-bit two's-complement integers per ds_add_u64 -- (m*v.x, m*v.y)
 // and (m, m*v.z) -- so a node costs 2 LDS atomics instead of 4 and 6 plain VALU instructions instead of 8 double-rate ones.
-// Every contribution is scaled below 2^22 (sums of 256 stay below 2^30) and rounded to nearest by v_cvt_rpi_i32_f32; the
+// The contributions are scaled so that the sum of the particles' bounds is below 2^30 (see the scales in the kernel) and
+// rounded to nearest by v_cvt_rpi_i32_f32; the
 // pair word is low + (high << 32) in 64-bit arithmetic, i.e. the high dword carries `high + (low >> 31)`, and the decode
 // undoes exactly that, so the two sums are exact integers and order-independent like the 64-bit ones.  What changes is the
-// quantum: 2^-22 of the largest contribution bound in the tile instead of 2^-42 -- the same order as the fp32 atomics of the
-// reference (2^-24 of each partial sum) for nodes that carry mass, but a node whose whole mass is below ~1e-6 of a
-// particle's (stencil corners at a free surface) is quantised visibly: see DESIGN.md 3.5 and
+// quantum: 2^-30 of the SUM of the contribution bounds of the tile's particles instead of 2^-42 of their maximum -- the
+// order of the fp32 atomics of the reference (2^-24 of each partial sum) for nodes that carry mass, but a node whose whole
+// mass is below ~1e-7 of a particle's (stencil corners at a free surface) is quantised visibly: see DESIGN.md 3.5 and
 // tests/test_mpm_hip.py::test_packed_scatter_parity.
 constexpr double kMagicD = 6755399441055744.0;            // 1.5 * 2^52
 
@@ -537,6 +538,21 @@ __device__ __forceinline__ unsigned dpp_umax(unsigned v) {
     // lanes the pattern does not feed (masked rows) read their own value: old = v, bound_ctrl off
     const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
     return max(v, o);
+}
+// Sum over the wave in the same network (fixed tree: reproducible).  Lanes a masked row pattern does not feed add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(o);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0xB1, 0xf>(v);
+    v = dpp_add<0x4E, 0xf>(v);
+    v = dpp_add<0x141, 0xf>(v);
+    v = dpp_add<0x140, 0xf>(v);     // every lane of a row of 16 holds the row sum
+    v = dpp_add<0x142, 0xa>(v);     // rows 1, 3 += rows 0, 2
+    v = dpp_add<0x143, 0xc>(v);     // rows 2, 3 += row 1 (= rows 0 + 1): lane 63 holds the wave sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_nonneg(float x) {
     unsigned v = __float_as_uint(x);
@@ -636,25 +652,36 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         }
     }
     // ---- workgroup bounds -> power-of-two scales ----
+    // One contribution of a particle is  w (mv_a + A_a . d) + T_a . g  with  w <= 0.75^3, |d_b| <= 1.5, |g_b| <= 0.75^2 (the
+    // B-spline weights and their derivatives in cell units), so  r_p = max_a [0.421875 (|mv_a| + 1.5 sum_b |A_ab|) +
+    // 0.5625 sum_b |T_ab|]  bounds every contribution of particle p.
+    //   exact mode: scale by the workgroup MAXIMUM of r_p to [2^41, 2^42): 256 contributions stay below 2^50.
+    //   packed mode: scale by the workgroup SUM of r_p to [2^29, 2^30): |any node sum| <= sum_p r_p < 2^30 whatever the
+    //     particle count, and the quantum is 2^-30 of the SUM instead of 2^-22 of 256 maxima -- typically 10-20x finer
+    //     (the sum of ~180 bounds of which most are well below the largest).  Same for the masses.
     float bp = 0.0f, bm = 0.0f;
-    if (TRACE && (sp.trace & 0x200)) { bp = 1.0f; bm = 1e-3f; }
+    if (TRACE && (sp.trace & 0x200)) { bp = PACK ? 256.0f : 1.0f; bm = PACK ? 0.256f : 1e-3f; }
     else {
         if (in.active) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float r = fabsf(in.mv[a]) + 1.5f * (fabsf(in.A.m[3 * a]) + fabsf(in.A.m[3 * a + 1]) + fabsf(in.A.m[3 * a + 2])) +
-                                (fabsf(in.T.m[3 * a]) + fabsf(in.T.m[3 * a + 1]) + fabsf(in.T.m[3 * a + 2]));
+                const float r = 0.421875f * (fabsf(in.mv[a]) + 1.5f * (fabsf(in.A.m[3 * a]) + fabsf(in.A.m[3 * a + 1]) + fabsf(in.A.m[3 * a + 2]))) +
+                                0.5625f * (fabsf(in.T.m[3 * a]) + fabsf(in.T.m[3 * a + 1]) + fabsf(in.T.m[3 * a + 2]));
                 bp = fmaxf(bp, r);
             }
-            bm = in.mass;
+            bm = 0.421875f * in.mass;
         }
-        bp = wave_max_nonneg(bp); bm = wave_max_nonneg(bm);
+        if (PACK) { bp = wave_sum(bp); bm = wave_sum(bm); }
+        else { bp = wave_max_nonneg(bp); bm = wave_max_nonneg(bm); }
         if ((tid & 63) == 0) { s_red[0][tid >> 6] = bp; s_red[1][tid >> 6] = bm; }
         __syncthreads();
         bp = s_red[0][0]; bm = s_red[1][0];
-        for (int w = 1; w < (nthr >> 6); ++w) { bp = fmaxf(bp, s_red[0][w]); bm = fmaxf(bm, s_red[1][w]); }
+        for (int w = 1; w < (nthr >> 6); ++w) {
+            if (PACK) { bp += s_red[0][w]; bm += s_red[1][w]; }     // (fixed order: the scale is reproducible)
+            else { bp = fmaxf(bp, s_red[0][w]); bm = fmaxf(bm, s_red[1][w]); }
+        }
     }
-    constexpr int kTop = PACK ? 21 : 41;
+    constexpr int kTop = PACK ? 29 : 41;
     const float sP = scale_for(bp, kTop), sM = scale_for(bm, kTop);
     PX_MPM_STAMP(3);
 
