@@ -58,6 +58,7 @@ struct Conv16Args {
     const float* pro_a; const float* pro_b; const float* gamma; const float* beta;
     int act;
     const uint4* w16;        // packed weights (header + hi planes + lo planes)
+    const float* wf;         // EXACT variant: fp32 weights [tap][c_in][c_out padded] (pixie_conv_pack_weights) instead of w16
     const float* bias;
     int cout, coutp;
     const float* residual; float* out;
@@ -106,7 +107,12 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned
 // buffer while waves 4-7 -- one per SIMD, next to a compute wave -- stage chunk c+1 into the other, so the loads,
 // the prologue arithmetic and the LDS writes are scheduled by the hardware into the gaps of the matrix pipe instead
 // of stopping it between chunks.  Without WS (256 threads) two workgroups share a CU and overlap only by chance.
-template <int KS, int MB, int NB, bool WS>
+// EX ("exact"): the same tiling, staging, prologue and epilogue with fp32 operands on v_mfma_f32_32x32x2_f32 -- every product
+// and every accumulation in fp32, as the reference's cuDNN/PyTorch fp32 convolution computes them (conv_precision = "f32").
+// The LDS tile holds the 16 channels of a chunk as fp32 planes [channel][voxel] (the same 64 bytes per voxel as the four
+// fp16 planes), a lane's B operand is one conflict-free ds_read_b32, its A operand one coalesced 4-byte load from the
+// [tap][c_in][c_out] weight array (L2-resident: 442 KB for the 64 -> 64 layer), fetched one tap ahead.
+template <int KS, int MB, int NB, bool WS, bool EX = false>
 __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     extern __shared__ uint4 smem16[];
     constexpr int PAD = (KS == 3) ? 1 : 0;
@@ -167,7 +173,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
         bound = __uint_as_float(*A.amax0);
         if (A.amax1) bound = fmaxf(bound, __uint_as_float(*A.amax1));
     }
-    const int ex = scale_exponent(bound);
+    const int ex = EX ? 0 : scale_exponent(bound);
     const float sx = pow2i(ex);
 
     f32x16 acc[MB][NB];
@@ -183,6 +189,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     const size_t plane = (size_t)(KS * KS * KS) * tap_stride;
     const uint4* wHi = A.w16 + kW16HeaderU4 + (size_t)kh * A.coutp + cout0 + l31;
     const uint4* wLo = wHi + plane;
+    const float* wF = A.wf + (size_t)kh * A.coutp + cout0 + l31;     // EX: channel (2 kp + kh) of the pair, row l31 of block mb
 
     constexpr int TAPS = KS * KS * KS;
     // ---- stage the 16-channel chunk starting at c_base into `buf`: one voxel x 16 channels per item, two items per
@@ -238,6 +245,18 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int vox = v0 + u * nthr;
+                    if (EX) {
+                        float* bF = reinterpret_cast<float*>(buf);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            float t = val[u][j];
+                            if (decltype(has_pro)::value) t = t * pa[j] + pb[j];
+                            t = t * gm[u] + bt[u];
+                            const float sc = ok[u] ? act16(t, decltype(act_c)::value) : 0.0f;   // zero padding AFTER the activation
+                            if (vox < A.CS) bF[j * A.CS + vox] = sc;
+                        }
+                        continue;
+                    }
                     f16x8 vh[2], vl[2];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
@@ -272,6 +291,48 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     // ---- MFMA over the taps of one chunk; the A fragments of tap t+1 are fetched during tap t ----
     auto mfma_chunk = [&](int c_base, const uint4* buf) {
         __builtin_amdgcn_s_setprio(3);   // the MFMA phase issues ahead of a co-resident workgroup's staging (+1 % measured)
+        if constexpr (EX) {
+            const float* ldsF = reinterpret_cast<const float*>(buf);
+            const size_t tapw = (size_t)A.cin * A.coutp;                 // floats per tap
+            const float* wc = wF + (size_t)c_base * A.coutp;
+            float a[8][MB], an[8][MB];
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) a[kp][mb] = wc[(size_t)(2 * kp) * A.coutp + mb * 32];
+#pragma unroll 1
+            for (int zy = 0; zy < KS * KS; ++zy) {
+                const int dz = zy / KS, dy = zy - dz * KS;
+                const int rowoff = (dz * A.HY + dy) * A.HX;
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) {
+                    const int tap = zy * KS + dx;
+                    const int nxt = (tap + 1 < TAPS) ? tap + 1 : tap;
+#pragma unroll
+                    for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) an[kp][mb] = wc[(size_t)nxt * tapw + (size_t)(2 * kp) * A.coutp + mb * 32];
+                    __builtin_amdgcn_sched_barrier(0);   // (as below: keep the next tap's A loads up here)
+#pragma unroll
+                    for (int kp = 0; kp < 8; ++kp) {
+                        float b[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) b[nb] = ldsF[voff[nb] + rowoff + dx + 2 * kp * A.CS];
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp][mb], b[nb], acc[mb][nb], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) a[kp][mb] = an[kp][mb];
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
         const uint4* ldsHi = buf;
         const uint4* ldsLo = buf + 2 * A.CS;
         const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
@@ -360,7 +421,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
             mfma_chunk(c_base, smem16);
             if (trace && ti < 13) tr[ti++] = wall_clock64();
         }
-        if (A.sk_w16) {
+        if (!EX && A.sk_w16) {
             // ---- the block's 1x1x1 skip convolution, in the same accumulators (so that out = conv(h) + skip(x) leaves this
             // launch; the skip tensor is never written or re-read).  acc holds sum (w s_w)(x s_x); the skip products carry
             // (s_w' s_x') instead, so acc is first multiplied by (s_w' s_x') / (s_w s_x) -- a power of two, exact.
@@ -452,7 +513,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     // registers: per output channel the sum and sum of squares over this workgroup's voxels (lane -> 32-lane DPP
     // reduction -> 4 waves through LDS) go to stats[tile][c_out_padded][2] with plain stores, and the tile's |x|max
     // to *out_amax; pixie_stats_finalize adds the tiles up in fp64.  That replaces one full read of the tensor.
-    const float inv = (!WS && A.sk_w16) ? inv2 : __uint_as_float(A.w16[0].x) * pow2i(-ex);
+    const float inv = EX ? 1.0f : ((!WS && A.sk_w16) ? inv2 : __uint_as_float(A.w16[0].x) * pow2i(-ex));
     if (A.partial) {   // split-K slice: raw partial sums; bias, residual and statistics belong to splitk_reduce_kernel
         float* dst = A.partial + (size_t)blockIdx.z * A.cout * OSP;
 #pragma unroll
@@ -570,6 +631,11 @@ template <int KS, int MB, int NB, bool WS>
 __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     conv3d_f16x3_body<KS, MB, NB, WS>(A);
 }
+// conv_precision = "f32": the exact-fp32 variant of the same body (v_mfma_f32_32x32x2_f32)
+template <int KS, int MB, int NB>
+__global__ __launch_bounds__(256, 2) void conv3d_exact_kernel(Conv16Args A) {
+    conv3d_f16x3_body<KS, MB, NB, false, true>(A);
+}
 // The dominant layer of the BASELINE network -- 64 -> 64 channels, 3^3, stride 1, on >= 128^3 voxels (the full-resolution
 // level: 41 % of a scene's FLOPs at 128^3; the 64^3 level has the same channel counts and stays on the template) -- under its own symbol, so that `rocprofv3 --kernel-trace --stats` reports it as
 // its own row instead of pooling it with the other shapes that share the <3,2,4> instantiation.  Same code, same results.
@@ -686,6 +752,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x3_pipe_kernel(Conv16Args A)
     const size_t plane = (size_t)TAPS * tap_stride;
     const uint4* wHi = A.w16 + kW16HeaderU4 + (size_t)kh * A.coutp + cout0 + l31;
     const uint4* wLo = wHi + plane;
+    const float* wF = A.wf + (size_t)kh * A.coutp + cout0 + l31;     // EX: channel (2 kp + kh) of the pair, row l31 of block mb
 
     const int nunits = 2 * A.CS;                 // 16-byte units per chunk: [kg 0..1][voxel]
     const int upt = (nunits + 255) >> 8;         // units per thread (10 for the 32x4x4 tile)
@@ -1107,6 +1174,52 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     PX_CONV16_CASE(1, 1, 4) PX_CONV16_CASE(1, 1, 2) PX_CONV16_CASE(1, 1, 1)
 #undef PX_CONV16_CASE
     return set_error("f16x3 conv: no kernel variant for ksize=%d MB=%d NB=%d", d->ksize, MB, NB);
+}
+
+template <int KS, int MB, int NB>
+static int launch_exact(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStream_t st) {
+    auto kern = conv3d_exact_kernel<KS, MB, NB>;
+    PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// 1 when pixie_conv3d_forward sends an exact-fp32 descriptor (d_w, no d_w16) through the tiled body above instead of the
+// first-generation kernel of conv3d_mfma.hip (odd channel counts, tiny test networks)
+bool conv3d_exact_tiled_ok(const pixie_conv_desc* d) {
+    const int cin = d->c0 + d->c1;
+    return cin % 16 == 0 && (d->stride == 1 || (d->stride == 2 && d->ksize == 3 && !d->upsample)) && getenv("PIXIE_CONV_EXACT_V1") == nullptr;
+}
+
+// called by pixie_conv3d_forward (conv3d_mfma.hip) for exact-fp32 descriptors that conv3d_exact_tiled_ok accepts
+int conv3d_exact_forward(const pixie_conv_desc* d, hipStream_t st) {
+    Conv16Args a{};
+    a.in0 = d->d_in0; a.in1 = d->d_in1; a.c0 = d->c0; a.cin = d->c0 + d->c1;
+    a.pro_a = d->d_pro_a; a.pro_b = d->d_pro_b; a.gamma = d->d_gamma; a.beta = d->d_beta; a.act = d->act;
+    a.wf = d->d_w; a.bias = d->d_bias;
+    a.residual = d->d_residual; a.out = d->d_out;
+    a.in_bound = 1.0f;
+    a.dbg = 0;
+    pixie_conv_desc probe = *d;
+    probe.d_workspace = nullptr;            // no split-K on this path: small layers shrink the tile instead
+    int MB = 0, NB = 0, slices = 1;
+    conv16_tiling(&probe, a, MB, NB, &slices);
+    size_t lds = (size_t)4 * a.CS * sizeof(uint4);      // 16 fp32 planes = the four 16-byte fp16 planes
+    PX_REQUIRE(lds <= 160 * 1024, "exact conv: tile needs %zu B of LDS", lds);
+    {   // room for the transposing epilogue, as long as two workgroups still fit on a CU
+        const size_t epi = ((size_t)4 * 32 * (NB * 32 + 4) + (size_t)4 * MB * 32 * 2) * sizeof(float);
+        if (epi <= 80 * 1024) { a.epi_lds = 1; if (lds < epi) lds = epi; }
+    }
+    const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)), 1u);
+#define PX_CONVEX_CASE(KS_, MB_, NB_) \
+    if (d->ksize == KS_ && MB == MB_ && NB == NB_) return launch_exact<KS_, MB_, NB_>(a, lds, grid, st);
+    PX_CONVEX_CASE(3, 2, 4) PX_CONVEX_CASE(3, 2, 2) PX_CONVEX_CASE(3, 2, 1)
+    PX_CONVEX_CASE(3, 1, 4) PX_CONVEX_CASE(3, 1, 2) PX_CONVEX_CASE(3, 1, 1)
+    PX_CONVEX_CASE(1, 2, 4) PX_CONVEX_CASE(1, 2, 2) PX_CONVEX_CASE(1, 2, 1)
+    PX_CONVEX_CASE(1, 1, 4) PX_CONVEX_CASE(1, 1, 2) PX_CONVEX_CASE(1, 1, 1)
+#undef PX_CONVEX_CASE
+    return set_error("exact conv: no kernel variant for ksize=%d MB=%d NB=%d", d->ksize, MB, NB);
 }
 
 }  // namespace pixie

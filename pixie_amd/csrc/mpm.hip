@@ -476,13 +476,13 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
 }
 
 // ---- fixed-point accumulation of the scatter ---------------------------------------------------------------------------
-// EXACT mode (default): 64-bit fixed point through the double-precision adder: the mantissa field of (x + 1.5 * 2^52) is
+// EXACT mode (set_scalar "scatter_bits" 64): 64-bit fixed point through the double-precision adder: the mantissa field of (x + 1.5 * 2^52) is
 // 2^51 + round(x) for |x| < 2^51, so ds_add_u64 of the raw bit patterns accumulates sum(round(x_i)) modulo 2^51 in the low
 // 51 bits whatever happens above them (the N copies of the exponent and of the 2^51 offset only carry upwards).  With every
 // contribution scaled below 2^42 and at most 256 of them per node the sum stays below 2^50 and is recovered by
 // sign-extending bit 50: two instructions per contribution (v_cvt_f64_f32, v_add_f64), exact integer accumulation,
 // order-independent.
-// PACKED mode (F_PACK32, set_scalar "scatter_bits" 32): two 32-bit two's-complement integers per ds_add_u64 -- (m*v.x, m*v.y)
+// PACKED mode (F_PACK32, the default; "scatter_bits" 32): two 32-bit two's-complement integers per ds_add_u64 -- (m*v.x, m*v.y)
 // and (m, m*v.z) -- so a node costs 2 LDS atomics instead of 4 and 6 plain VALU instructions instead of 8 double-rate ones.
 // The contributions are scaled so that the sum of the particles' bounds is below 2^30 (see the scales in the kernel) and
 // rounded to nearest by v_cvt_rpi_i32_f32; the
@@ -1312,7 +1312,7 @@ struct pixie_mpm {
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
     int2* nbr_table = nullptr;               // 28 int2 per active block (see MpmPtrs)
-    int scatter_bits = 64;                   // 64: exact fixed point (4 LDS atomics per node); 32: packed pairs (2 per node)
+    int scatter_bits = 32;                   // 32 (default): packed pairs of 32-bit sums, 2 LDS atomics per node; 64: exact 64-bit fixed point, 4 per node
     int wide = -1;                           // -1 auto: the latency-optimised variant when the scene cannot fill the chip; 0/1 forced
     int n_cus = 256;
     int n_active = 0;

@@ -360,6 +360,18 @@ class MPM_Simulator_WARP:
         self._pending += int(n_substeps)
         self.flush()
 
+    @property
+    def scatter_bits(self):
+        """Accumulation mode of the P2G scatter (csrc/mpm.hip).  32 (default): pairs of 32-bit fixed-point sums per LDS atomic
+        -- half the atomics, quantum 2^-30 of the summed contribution bounds of a 256-particle work item, the noise level of
+        the reference's fp32 atomics; 64: exact 64-bit fixed point (quantum 2^-42), 20 % slower.  Both are integer sums:
+        order-independent and bit-reproducible."""
+        return int(self._get_scalar("scatter_bits"))
+
+    @scatter_bits.setter
+    def scatter_bits(self, bits):
+        self._set_scalar("scatter_bits", int(bits))
+
     def _warn_if_particles_lost(self):
         """Mass leaving the simulation must not be silent: the count read back at the last re-binning (no sync)."""
         out = C.c_double(0.0)
