@@ -355,6 +355,17 @@ int64_t pixie_field_points_scratch_bytes(const pixie_field_desc* field);
 int pixie_field_points(const pixie_field_desc* field, int64_t capacity, float* d_xyz /* [n][3] */, float* d_density, float* d_E,
                        float* d_nu, int32_t* d_material, float* d_conf, int64_t* d_count, void* d_scratch, void* stream);
 
+/* Density clustering of the "stationary" particles -- sklearn.cluster.DBSCAN(eps, min_samples).fit_predict at
+ * PhysGaussian/material_field.py:405-406 -- up to the numbering: d_root[i] (ORIGINAL order) = the lowest original index among
+ * the core points of point i's cluster (core points: their component; border points: the smallest such root among the core
+ * points within eps), or -1 for noise.  Clusters numbered by ascending root are DBSCAN's labels.  The caller bins the points:
+ * d_pos_sorted [n][3] sorted by cell id ((cx * ny + cy) * nz + cz of floor((p - lo) / cell_size), clamped), d_orig_index[s] the
+ * original index of sorted point s, d_cell_start[nx*ny*nz + 1] the first sorted index of every cell; cell_size >= eps.
+ * d_core_scratch / d_parent_scratch: n int32 each.  Distances in float64 on the float32 coordinates.  Three launches. */
+int pixie_dbscan_roots(const float* d_pos_sorted, const int32_t* d_orig_index, const int32_t* d_cell_start, int n, int nx, int ny, int nz,
+                       const double lo[3], double cell_size, double eps, int min_samples, int32_t* d_core_scratch,
+                       int32_t* d_parent_scratch, int32_t* d_root, void* stream);
+
 /* ======================================================================================
  * (D) Particle pre-pass of the MPM program: replaces the Taichi kernels of
  *     PG/particle_filling/filling.py that gs_simulation.py:442-482 runs before the solver is created.

@@ -98,3 +98,44 @@ def field_to_particles(pred: np.ndarray, mask: np.ndarray, min_bounds, max_bound
     """The whole transfer: network output (11,D,H,W) + occupancy mask -> per-particle material properties."""
     cloud = voxel_point_cloud(unscale_prediction(pred, ranges), mask, min_bounds, max_bounds)
     return knn_assign(cloud, particle_pos, k, nn_distance_threshold, weighted)
+
+
+def dbscan_labels(points: np.ndarray, eps: float, min_samples: int) -> np.ndarray:
+    """The labels sklearn.cluster.DBSCAN(eps, min_samples).fit_predict assigns (PhysGaussian/material_field.py:405-406),
+    restated without sklearn as a radius graph (tests/test_bc_construction.py pins it to sklearn itself): a point is a core
+    point when its closed eps-ball holds >= min_samples points; clusters are the connected components of the core points,
+    numbered in the order of their lowest-index core point; a border point joins the earliest-numbered cluster that has a
+    core point within eps; everything else is noise (-1)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import cKDTree
+
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = len(pts)
+    labels = np.full(n, -1, dtype=np.int64)
+    if n == 0:
+        return labels
+    pairs = cKDTree(pts).query_pairs(float(eps), output_type="ndarray")           # i < j, |pi - pj| <= eps
+    degree = np.bincount(pairs.ravel(), minlength=n) + 1                          # the point itself counts
+    core = degree >= min_samples
+    if not core.any():
+        return labels
+    both = core[pairs[:, 0]] & core[pairs[:, 1]]
+    graph = coo_matrix((np.ones(int(both.sum()), dtype=np.int8), (pairs[both, 0], pairs[both, 1])), shape=(n, n))
+    _, comp = connected_components(graph, directed=False)
+    core_idx = np.flatnonzero(core)
+    first_core = np.full(comp.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first_core, comp[core_idx], core_idx)                           # lowest core index of each component
+    order = np.argsort(first_core, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    labels[core_idx] = rank[comp[core_idx]]
+    # border points: earliest cluster among their core neighbours
+    edge = np.concatenate([pairs[core[pairs[:, 1]] & ~core[pairs[:, 0]]],
+                           pairs[core[pairs[:, 0]] & ~core[pairs[:, 1]]][:, ::-1]])   # (border, core)
+    if len(edge):
+        best = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+        np.minimum.at(best, edge[:, 0], labels[edge[:, 1]])
+        hit = best != np.iinfo(np.int64).max
+        labels[hit] = best[hit]
+    return labels

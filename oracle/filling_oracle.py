@@ -5,8 +5,9 @@ Restates third_party/PhysGaussian/particle_filling/filling.py: compute_density :
 fill_dense_grids :95-121 (which cells, how many points -- the points themselves are ti.random()), collision_search :124-149,
 collision_times :152-183, internal_filling :186-244, compute_particle_volume :257-266, get_attr_from_closest :383-403.
 PARITY UNPINNED: Taichi is not installed here and the reference holds no vectors for these kernels; the restatement is
-float64 and is anchored by closed-form cases in tests/test_filling_oracle.py (a single isotropic Gaussian's density, a
-hollow shell whose interior must fill, a shell open on the excluded side).
+float64 and is anchored by closed-form and brute-force cases in tests/test_filling_oracle.py (a single isotropic Gaussian's
+density; one rotated anisotropic Gaussian re-computed cell by cell from the definition; a hollow shell whose interior must
+fill; a shell open on the excluded side; a torus, whose filled set must be the tube interior of the implicit equation).
 """
 from __future__ import annotations
 

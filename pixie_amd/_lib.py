@@ -138,6 +138,7 @@ SIGNATURES = {
     "pixie_fill_internal_cells": (_I, [_VP, _VP, _I, _D, _I, _I, _I, _D, _VP, _I64, _VP, C.c_uint32, _VP]),
     "pixie_particle_volume": (_I, [_VP, _I, _I, _D, _VP, _VP, _VP]),
     "pixie_nearest_particle": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
+    "pixie_dbscan_roots": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, C.POINTER(_D), _D, _D, _I, _VP, _VP, _VP, _VP]),
     "pixie_field_to_particles": (_I, [C.POINTER(FieldDesc), _VP, _I, _I, _D, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 

@@ -321,3 +321,121 @@ extern "C" int pixie_field_to_particles(const pixie_field_desc* f, const float* 
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ======================================================================================================================
+// Density clustering of the "stationary" particles (PhysGaussian/material_field.py:405-406: sklearn.cluster.DBSCAN(eps,
+// min_samples).fit_predict) on the device.  The caller bins the points on a lattice of cell size >= eps (a sort by cell
+// id -- torch); every point then looks at the 27 cells around its own:
+//   core     a point whose closed eps-ball holds >= min_samples points (itself included);
+//   clusters connected components of the core points under "within eps" -- lock-free union-find that always links
+//            the larger root under the smaller, so a component's root is its LOWEST-INDEX core point, which is also what
+//            DBSCAN numbers clusters by;
+//   border   a non-core point takes the smallest root among the core points within eps of it; noise gets -1.
+// Distances are evaluated in float64 on the float32 coordinates, as scipy / sklearn do.
+namespace pixie {
+
+struct DbscanArgs {
+    const float* pos;        // [n][3], SORTED by lattice cell
+    const int* orig;         // [n]: original index of sorted point s
+    const int* cell_start;   // [nx*ny*nz + 1]
+    int n, nx, ny, nz;
+    float lo[3];
+    float inv_cell;
+    double eps2;
+    int min_samples;
+    int* core;               // [n] by sorted index
+    int* parent;             // [n] by ORIGINAL index
+    int* root;               // [n] by ORIGINAL index: output
+};
+
+__device__ __forceinline__ int db_cell(const DbscanArgs& A, float v, int axis, int dim) {
+    int c = (int)floorf((v - A.lo[axis]) * A.inv_cell);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+// calls visit(t) for every sorted index t != s whose point lies within eps of point s
+template <class F>
+__device__ __forceinline__ void db_for_neighbours(const DbscanArgs& A, int s, F visit) {
+    const double px = A.pos[3 * s], py = A.pos[3 * s + 1], pz = A.pos[3 * s + 2];
+    const int cx = db_cell(A, (float)px, 0, A.nx), cy = db_cell(A, (float)py, 1, A.ny), cz = db_cell(A, (float)pz, 2, A.nz);
+    for (int ix = max(cx - 1, 0); ix <= min(cx + 1, A.nx - 1); ++ix)
+        for (int iy = max(cy - 1, 0); iy <= min(cy + 1, A.ny - 1); ++iy) {
+            // the three z-neighbours are contiguous in the cell order: one range
+            const int c0 = (ix * A.ny + iy) * A.nz + max(cz - 1, 0), c1 = (ix * A.ny + iy) * A.nz + min(cz + 1, A.nz - 1);
+            for (int t = A.cell_start[c0]; t < A.cell_start[c1 + 1]; ++t) {
+                if (t == s) continue;
+                const double dx = (double)A.pos[3 * t] - px, dy = (double)A.pos[3 * t + 1] - py, dz = (double)A.pos[3 * t + 2] - pz;
+                if (dx * dx + dy * dy + dz * dz <= A.eps2) visit(t);
+            }
+        }
+}
+
+__global__ __launch_bounds__(128) void dbscan_core_kernel(DbscanArgs A) {
+    const int s = blockIdx.x * 128 + threadIdx.x;
+    if (s >= A.n) return;
+    int degree = 1;   // the point itself counts
+    db_for_neighbours(A, s, [&](int) { ++degree; });
+    A.core[s] = degree >= A.min_samples ? 1 : 0;
+    A.parent[A.orig[s]] = A.orig[s];
+}
+
+__device__ __forceinline__ int db_find(int* parent, int i) {
+    int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != i) {
+        i = p;
+        p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return i;
+}
+
+__global__ __launch_bounds__(128) void dbscan_union_kernel(DbscanArgs A) {
+    const int s = blockIdx.x * 128 + threadIdx.x;
+    if (s >= A.n || !A.core[s]) return;
+    const int me = A.orig[s];
+    db_for_neighbours(A, s, [&](int t) {
+        if (!A.core[t]) return;
+        int a = me, b = A.orig[t];
+        while (true) {   // link the larger root under the smaller one; retry when somebody else moved a root meanwhile
+            a = db_find(A.parent, a); b = db_find(A.parent, b);
+            if (a == b) break;
+            if (a < b) { const int tmp = a; a = b; b = tmp; }
+            const int old = atomicMin(&A.parent[a], b);
+            if (old == a) break;
+            a = old;
+        }
+    });
+}
+
+__global__ __launch_bounds__(128) void dbscan_label_kernel(DbscanArgs A) {
+    const int s = blockIdx.x * 128 + threadIdx.x;
+    if (s >= A.n) return;
+    const int me = A.orig[s];
+    if (A.core[s]) { A.root[me] = db_find(A.parent, me); return; }
+    int best = 0x7fffffff;
+    db_for_neighbours(A, s, [&](int t) { if (A.core[t]) best = min(best, db_find(A.parent, A.orig[t])); });
+    A.root[me] = best == 0x7fffffff ? -1 : best;
+}
+
+}  // namespace pixie
+
+extern "C" int pixie_dbscan_roots(const float* d_pos_sorted, const int32_t* d_orig_index, const int32_t* d_cell_start, int n, int nx, int ny,
+                                  int nz, const double lo[3], double cell_size, double eps, int min_samples, int32_t* d_core_scratch,
+                                  int32_t* d_parent_scratch, int32_t* d_root, void* stream) {
+    PX_REQUIRE(n >= 0 && nx > 0 && ny > 0 && nz > 0 && eps > 0 && cell_size >= eps && min_samples >= 1 && lo, "pixie_dbscan_roots: bad arguments");
+    if (n == 0) return 0;
+    PX_REQUIRE(d_pos_sorted && d_orig_index && d_cell_start && d_core_scratch && d_parent_scratch && d_root, "pixie_dbscan_roots: null argument");
+    DbscanArgs A{};
+    A.pos = d_pos_sorted; A.orig = d_orig_index; A.cell_start = d_cell_start; A.n = n; A.nx = nx; A.ny = ny; A.nz = nz;
+    for (int k = 0; k < 3; ++k) A.lo[k] = (float)lo[k];
+    A.inv_cell = (float)(1.0 / cell_size);
+    A.eps2 = eps * eps;
+    A.min_samples = min_samples;
+    A.core = d_core_scratch; A.parent = d_parent_scratch; A.root = d_root;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    hipLaunchKernelGGL(dbscan_core_kernel, grid, block, 0, st, A);
+    hipLaunchKernelGGL(dbscan_union_kernel, grid, block, 0, st, A);
+    hipLaunchKernelGGL(dbscan_label_kernel, grid, block, 0, st, A);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -92,50 +92,43 @@ def apply_material_field_to_solver(mpm_solver, pred: torch.Tensor, mask: torch.T
 
 # ----------------------------------------------------------------------------------------------------------------------
 # Boundary conditions derived from the transferred field (third_party/PhysGaussian/material_field.py:364-550).
-# Both run once per scene on a few numbers, so they stay host-side like the reference's; the density clustering is
-# restated without sklearn as a radius graph over the stationary particles.
-def dbscan_labels(points: np.ndarray, eps: float, min_samples: int) -> np.ndarray:
+def dbscan_labels(points, eps: float, min_samples: int) -> torch.Tensor:
     """Labels as sklearn.cluster.DBSCAN(eps, min_samples).fit_predict assigns them (the reference's call,
-    material_field.py:405-406): a point is a core point when its closed eps-ball holds >= min_samples points; clusters are
-    the connected components of the core points and are numbered in the order of their lowest-index core point; a border
-    point joins the earliest-numbered cluster that has a core point within eps; everything else is noise (-1)."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
-    from scipy.spatial import cKDTree
-
-    pts = np.ascontiguousarray(points, dtype=np.float64)
-    n = len(pts)
-    labels = np.full(n, -1, dtype=np.int64)
+    material_field.py:405-406), computed on the device (csrc/field_transfer.hip: pixie_dbscan_roots): a point is a core
+    point when its closed eps-ball holds >= min_samples points; clusters are the connected components of the core points
+    and are numbered in the order of their lowest-index core point; a border point joins the earliest-numbered cluster that
+    has a core point within eps; everything else is noise (-1).  `points`: (n, 3) tensor or array; returns int64 labels on
+    the device.  The points are binned on a lattice of cell size >= eps here (one sort), the kernels search 27 cells."""
+    if not torch.cuda.is_available():
+        raise _lib.PixieHipError("dbscan_labels runs on a HIP device only (no CPU fallback)")
+    dev = points.device if isinstance(points, torch.Tensor) and points.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    pts = torch.as_tensor(points).detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    n = pts.shape[0]
+    labels = torch.full((n,), -1, dtype=torch.int64, device=dev)
     if n == 0:
         return labels
-    pairs = cKDTree(pts).query_pairs(float(eps), output_type="ndarray")           # i < j, |pi - pj| <= eps
-    degree = np.bincount(pairs.ravel(), minlength=n) + 1                          # the point itself counts
-    core = degree >= min_samples
-    if not core.any():
-        return labels
-    both = core[pairs[:, 0]] & core[pairs[:, 1]]
-    graph = coo_matrix((np.ones(int(both.sum()), dtype=np.int8), (pairs[both, 0], pairs[both, 1])), shape=(n, n))
-    _, comp = connected_components(graph, directed=False)
-    core_idx = np.flatnonzero(core)
-    first_core = np.full(comp.max() + 1, n, dtype=np.int64)
-    np.minimum.at(first_core, comp[core_idx], core_idx)                           # lowest core index of each component
-    order = np.argsort(first_core, kind="stable")
-    rank = np.empty_like(order)
-    rank[order] = np.arange(len(order))
-    labels[core_idx] = rank[comp[core_idx]]
-    # border points: earliest cluster among their core neighbours
-    edge = np.concatenate([pairs[core[pairs[:, 1]] & ~core[pairs[:, 0]]],
-                           pairs[core[pairs[:, 0]] & ~core[pairs[:, 1]]][:, ::-1]])   # (border, core)
-    if len(edge):
-        best = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
-        np.minimum.at(best, edge[:, 0], labels[edge[:, 1]])
-        hit = best != np.iinfo(np.int64).max
-        labels[hit] = best[hit]
+    lo = pts.amin(dim=0)
+    extent = float((pts.amax(dim=0) - lo).max())
+    cell = max(float(eps) * (1.0 + 1e-6), extent / 256.0)          # <= 257^3 cells whatever the extent
+    inv = float(np.float32(1.0 / cell))                             # (the kernels recompute the cells with this float32 arithmetic)
+    cells = torch.floor((pts - lo) * inv).to(torch.int64)
+    dims = (cells.amax(dim=0) + 1).tolist()
+    nx, ny, nz = (int(d) for d in dims)
+    cid = (cells[:, 0] * ny + cells[:, 1]) * nz + cells[:, 2]
+    order = torch.argsort(cid, stable=True)
+    cell_start = torch.searchsorted(cid[order].contiguous(), torch.arange(nx * ny * nz + 1, device=dev)).to(torch.int32).contiguous()
+    pos_sorted = pts[order].contiguous()
+    orig = order.to(torch.int32).contiguous()
+    core, parent, root = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lo64 = (C.c_double * 3)(*[float(v) for v in lo.tolist()])
+    check(_lib.load().pixie_dbscan_roots(p(pos_sorted), p(orig), p(cell_start), n, nx, ny, nz, lo64, float(1.0 / inv), float(eps),
+                                         int(min_samples), p(core), p(parent), p(root), _lib.current_stream_ptr()), "pixie_dbscan_roots")
+    found = root >= 0
+    if bool(found.any()):
+        roots = torch.unique(root[found])                       # ascending: DBSCAN's cluster numbering
+        labels[found] = torch.searchsorted(roots, root[found].contiguous())
     return labels
-
-
-def _host_array(a) -> np.ndarray:
-    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
 
 
 def handle_stationary_clusters(mpm_solver, positions, material_ids, eps: float = 0.03, min_samples: int = 10,
@@ -143,30 +136,36 @@ def handle_stationary_clusters(mpm_solver, positions, material_ids, eps: float =
                                only_handle_largest_cluster: bool = True, debug_output_dir=None, debug: bool = False):
     """material_field.py:364-479: one velocity-zero cuboid (reset=1) around every density cluster of the particles whose
     material is "stationary" -- or only around the largest one.  Returns the list of BC records the reference returns.
-    (`debug_output_dir` / `debug` are accepted for signature compatibility; the PLY dumps are not reproduced.)"""
-    pos = _host_array(positions)
-    mat = _host_array(material_ids)
+    The clustering and the clusters' bounding boxes are computed where the particles live; six numbers per cluster reach
+    the host.  (`debug_output_dir` / `debug` are accepted for signature compatibility; the PLY dumps are not reproduced.)"""
+    if not torch.cuda.is_available():
+        raise _lib.PixieHipError("handle_stationary_clusters runs on a HIP device only (no CPU fallback)")
+    dev = positions.device if isinstance(positions, torch.Tensor) and positions.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    pos = torch.as_tensor(positions).detach().to(dev).reshape(-1, 3)
+    mat = torch.as_tensor(material_ids).detach().to(dev).reshape(-1)
     stationary = pos[mat == STATIONARY_ID]
-    if len(stationary) == 0:
+    if stationary.shape[0] == 0:
         return []
     labels = dbscan_labels(stationary, eps, min_samples)
-    ids = np.unique(labels[labels >= 0])
-    if len(ids) == 0:
+    n_clusters = int(labels.max()) + 1
+    if n_clusters <= 0:
         return []
-    sizes = {int(i): int(np.sum(labels == i)) for i in ids}
-    if only_handle_largest_cluster and len(ids) > 1:
-        ids = np.array([max(sizes.items(), key=lambda kv: kv[1])[0]])            # first maximum, as the reference
+    counts = torch.bincount(labels[labels >= 0], minlength=n_clusters)
+    ids = list(range(n_clusters))
+    if only_handle_largest_cluster and n_clusters > 1:
+        ids = [int(torch.argmax(counts))]                                        # first maximum, as the reference
+    sizes = counts.tolist()
     records = []
     for cid in ids:
         cluster = stationary[labels == cid]
-        lo, hi = cluster.min(axis=0), cluster.max(axis=0)
+        lo, hi = cluster.amin(dim=0).cpu().numpy(), cluster.amax(dim=0).cpu().numpy()     # (the particles' own dtype, as the reference)
         center = (0.5 * (lo + hi)).tolist()
         half = (0.5 * (hi - lo) + buffer).tolist()
         mpm_solver.set_velocity_on_cuboid(point=center, size=half, velocity=[0.0, 0.0, 0.0], start_time=start_time,
                                           end_time=end_time, reset=1)
         records.append({"type": "stationary_cluster", "cluster_id": int(cid), "point": center, "size": half,
                         "velocity": [0.0, 0.0, 0.0], "start_time": start_time, "end_time": end_time, "reset": 1,
-                        "cluster_size": sizes[int(cid)]})
+                        "cluster_size": int(sizes[cid])})
     return records
 
 

@@ -8,7 +8,20 @@ import pytest
 import torch
 
 from oracle import filling_oracle as fo
-from tests.test_filling_oracle import shell_scene
+
+
+def shell_scene(n=6000, seed=11, open_bottom=False):
+    """The product's own test scene (not the oracle's anchors'): Gaussians on a tri-axial ellipsoid shell off the box centre,
+    anisotropic covariances with all three off-diagonal terms."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    if open_bottom:
+        d = d[d[:, 2] > -0.6]
+    pos = np.array([0.48, 0.53, 0.5]) + d * np.array([0.31, 0.26, 0.29])
+    s2 = rng.uniform(0.012, 0.019, len(pos)) ** 2
+    cov = np.zeros((len(pos), 6)); cov[:, 0] = 1.1 * s2; cov[:, 3] = 1.25 * s2; cov[:, 5] = 0.85 * s2
+    cov[:, 1] = 0.12 * s2; cov[:, 2] = -0.08 * s2; cov[:, 4] = 0.05 * s2
+    return pos, np.full(len(pos), 0.9), cov
 
 pytestmark = pytest.mark.gpu
 
@@ -57,8 +70,9 @@ def test_fill_particles_matches_oracle(hip_device, open_bottom, exclude, ppc):
     again = fill_particles(pos32, op32[:, None], cov32, n, 200_000, dx, dens_thr, search_thr, ppc, exclude, 4, seed=3)
     other = fill_particles(pos32, op32[:, None], cov32, n, 200_000, dx, dens_thr, search_thr, ppc, exclude, 4, seed=4)
     assert len(again) == len(out) == len(other)
+    assert torch.equal(again, out)        # row for row: the new particles come back in a canonical order
     sort = lambda t: t[len(pos32):].cpu().numpy()[np.lexsort(t[len(pos32):].cpu().numpy().T)]
-    assert np.array_equal(sort(again), sort(out)) and not np.array_equal(sort(other), sort(out))
+    assert not np.array_equal(sort(other), sort(out))
 
 
 def test_boundary_and_overflow(hip_device):

@@ -64,3 +64,71 @@ def test_volume_and_nearest():
     new = rng.uniform(0, 1, size=(50, 3))
     idx = fo.nearest(pos, new)
     assert (np.linalg.norm(new - pos[idx], axis=1) <= np.linalg.norm(new[:, None] - pos[None], axis=2).min(1) + 1e-15).all()
+
+
+def test_anisotropic_gaussian_against_brute_force():
+    """Second anchor for densify: ONE rotated, strongly anisotropic Gaussian, every touched cell re-computed from the
+    definition (filling.py:13-23, :60-92) with nothing shared with the oracle's vectorised code: explicit inverse of the
+    covariance, a Python loop over the cell's eight corners, the reach ceil(sqrt(largest eigenvalue) / dx) from numpy's
+    eigvalsh."""
+    dx, n = 0.05, 20
+    ang = 0.7
+    R = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]]) @ \
+        np.array([[1.0, 0.0, 0.0], [0.0, np.cos(0.4), -np.sin(0.4)], [0.0, np.sin(0.4), np.cos(0.4)]])
+    Cm = R @ np.diag([0.11 ** 2, 0.03 ** 2, 0.015 ** 2]) @ R.T
+    pos = np.array([[0.512, 0.467, 0.533]])
+    cov6 = np.array([[Cm[0, 0], Cm[0, 1], Cm[0, 2], Cm[1, 1], Cm[1, 2], Cm[2, 2]]])
+    count, dens = fo.densify(pos, [0.6], cov6, n, dx)
+    ci = np.floor(pos[0] / dx).astype(int)
+    assert count.sum() == 1 and count[tuple(ci)] == 1
+    Cinv = np.linalg.inv(Cm)
+    reach = int(np.ceil(np.sqrt(np.linalg.eigvalsh(Cm).max()) / dx))
+    assert reach == 3
+    checked = 0
+    for i in range(n):
+        for j in range(n):
+            for k in range(n):
+                inside = max(abs(i - ci[0]), abs(j - ci[1]), abs(k - ci[2])) <= reach
+                if not inside:
+                    assert dens[i, j, k] == 0.0
+                    continue
+                acc = 0.0
+                for a in (0, 1):
+                    for b in (0, 1):
+                        for c in (0, 1):
+                            d = pos[0] - np.array([i + a, j + b, k + c]) * dx
+                            acc += np.exp(-0.5 * d @ Cinv @ d)
+                assert abs(dens[i, j, k] - 0.6 * acc / 8.0) < 1e-13
+                checked += 1
+    assert checked == (2 * reach + 1) ** 3
+
+
+def torus_scene(n=40000, seed=3, R=0.28, r=0.11):
+    """Points on a torus surface (axis z) centred in the unit box, small isotropic Gaussians."""
+    rng = np.random.default_rng(seed)
+    u, v = rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n)
+    pos = 0.5 + np.stack([(R + r * np.cos(v)) * np.cos(u), (R + r * np.cos(v)) * np.sin(u), r * np.sin(v)], 1)
+    s2 = np.full(n, 0.012 ** 2)
+    cov = np.zeros((n, 6)); cov[:, 0] = s2; cov[:, 3] = s2; cov[:, 5] = s2
+    return pos, np.full(n, 0.9), cov
+
+
+def test_torus_interior_by_ray_parity():
+    """Second anchor for internal_cells: a torus (genus 1).  Cells in the central hole see the shell along +-x and +-y but
+    not along +-z; cells of the tube see it in all six directions and cross it once along the parity ray.  The filled set
+    must be the tube's interior as the implicit equation gives it -- every filled cell inside the tube, every cell
+    comfortably inside the tube filled, nothing in the hole."""
+    n, dx = 48, 1.0 / 48
+    R, r = 0.28, 0.11
+    pos, op, cov = torus_scene(R=R, r=r)
+    count, dens = fo.densify(pos, op, cov, n, dx)
+    filled = fo.internal_cells(count, dens, 1.0, exclude_dir=-1, ray_cast_dir=4)
+    c = (np.indices((n, n, n)).reshape(3, -1).T + 0.5) * dx - 0.5
+    rho = np.sqrt((np.sqrt(c[:, 0] ** 2 + c[:, 1] ** 2) - R) ** 2 + c[:, 2] ** 2).reshape(n, n, n)     # distance to the tube's centre circle
+    assert filled.sum() > 2000
+    # nothing outside the tube (the hole included) is filled -- up to the splat's own thickness: empty cells whose density
+    # exceeds the threshold count as solid AND as fillable (internal_filling tests the particle count only, filling.py:204)
+    assert (rho[filled] < r + 2.0 * dx).all()
+    deep = rho < r - 3.5 * dx                               # cells well inside, clear of the splatted shell
+    assert deep.sum() > 800 and filled[deep].mean() > 0.999
+    assert not filled[n // 2, n // 2, n // 2]               # the centre of the hole
