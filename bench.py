@@ -204,7 +204,7 @@ class ConvProfiler:
             if v == 9324:
                 return "conv3d_f16x3_c64_fullres_kernel"
             if not v:
-                return "conv3d_mfma_kernel (exact fp32)"
+                return "conv3d_exact_kernel (exact fp32: the tiled body on v_mfma_f32_32x32x2_f32)"
             return f"conv3d_f16x3_kernel<{v // 100},{(v // 10) % 10},{v % 10}>" + (f" x{sl} slices" if sl > 1 else "")
         return {name(v, sl):
                 {"launches": n, "avg_ms": round(t / n, 4)} for (v, sl), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])}
@@ -332,7 +332,7 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
                     "mfma_hw_frac_of_sustained": (round(3 * ach / sustained_f16_mfma_random_tflops()[0], 4)
                                                   if sustained_f16_mfma_random_tflops()[0] else None)}
         else:
-            roof = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,2,4,4> (64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
+            roof = {"bound": "mfma", "kernel": "conv3d_exact_kernel<3,2,4> (64->64 3^3 conv, %d^3; v_mfma_f32_32x32x2_f32)" % D, "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl}
     conv_ms = sum(v[0] for v in agg.values()) / 2.0

@@ -779,13 +779,18 @@ def test_network_256_cube_128_features(hip_device):
     res = {}
     for prec in ("f16x3", "f32"):
         seg.conv_precision = cont.conv_precision = prec
-        for _ in range(2):                 # first call eager, second call captures the graphs; the third one replays
-            predict_material_field(seg, cont, feat)
+        for call in range(2):              # first call eager, second call captures the graphs; the third one replays
+            _, _, lg, cp = predict_material_field(seg, cont, feat)
+            assert bool(torch.isfinite(lg).all()) and bool(torch.isfinite(cp).all()), \
+                f"{prec} call {call}: logits finite {bool(torch.isfinite(lg).all())}, regression finite {bool(torch.isfinite(cp).all())}"
+            del lg, cp
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         combined, seg_pred, logits, cpred = predict_material_field(seg, cont, feat)
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0)
+        assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(cpred).all()), \
+            f"{prec} replay: logits finite {bool(torch.isfinite(logits).all())}, regression finite {bool(torch.isfinite(cpred).all())}"
         assert bool(torch.isfinite(combined).all()) and bool((combined[0, 3:].sum(0) == 1).all())
         res[prec] = (logits.clone(), cpred.clone(), seg_pred.clone())
         print(f"  {prec}: 256^3 x 128 two-network forward {ms:.0f} ms = {D ** 3 / ms / 1e3:.1f} M voxels/s; peak device memory {torch.cuda.max_memory_allocated() / 2 ** 30:.0f} GiB")
