@@ -668,6 +668,11 @@ void refresh_bounds(pixie_unet* net, void* stream) {
     }
 }
 
+__global__ void zero_head_kernel(uint4* p, int64_t n16) {   // head_bytes is a multiple of kSlotAlign (256)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 constexpr int64_t kSlotAlign = 256;
 int64_t slot_region_bytes(int n_slots) { return ((int64_t)n_slots * 4 + kSlotAlign - 1) / kSlotAlign * kSlotAlign; }
 int64_t zsum_region_bytes(int64_t n_doubles) { return (n_doubles * 8 + kSlotAlign - 1) / kSlotAlign * kSlotAlign; }
@@ -785,7 +790,13 @@ extern "C" int pixie_unet_forward(pixie_unet* h, const float* d_feat, const floa
             ex.slot_cap = sized.slots;
             ex.zsums = reinterpret_cast<double*>(static_cast<char*>(d_workspace) + slot_bytes);
             ex.zsum_cap = sized.zsum_doubles;
-            if (hipMemsetAsync(d_workspace, 0, (size_t)head_bytes, as_stream(stream)) != hipSuccess) fail("pixie_unet_forward: hipMemsetAsync failed");
+            // Zeroed by a KERNEL, not hipMemsetAsync: as a node of a captured graph the memset did not reliably complete before
+            // the kernels that follow it on ROCm 7.2 (replays of the f16x3 pass, whose first kernel already adds into this
+            // region, gave wrong results at random once the workspace held a previous replay's values:
+            // scripts/unet_soak.py, profiles/r3i_graph_replay_bisect.txt).  A kernel node has ordinary dependencies.
+            hipLaunchKernelGGL(zero_head_kernel, dim3((unsigned)((head_bytes / 16 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                               static_cast<uint4*>(d_workspace), head_bytes / 16);
+            if (hipGetLastError() != hipSuccess) fail("pixie_unet_forward: clearing the workspace head failed");
             ex.arena.reset(static_cast<char*>(d_workspace) + head_bytes, workspace_bytes - head_bytes);
             TP out = ex.forward(d_feat, d_proj0, d, hh, w, d_out);
         };

@@ -527,13 +527,18 @@ class UNetHandle:
             raise _lib.PixieHipError(self.lib.pixie_last_error().decode())
         return n
 
-    def forward(self, feat: Optional[torch.Tensor], proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """feat (C_feat, D, H, W) float32 (or None with proj0 = the output of projector.net[0]) -> (out_channels, D, H, W)."""
+    def forward(self, feat: Optional[torch.Tensor], proj0: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat (C_feat, D, H, W) float32 (or None with proj0 = the output of projector.net[0]) -> (out_channels, D, H, W).
+        `workspace`: a caller-owned uint8 device tensor of at least workspace_bytes(d, h, w) bytes (any content); default:
+        allocated per call."""
         src = proj0 if proj0 is not None else feat
         d, h, w = (int(v) for v in src.shape[1:])
         out = torch.empty((self.cfg.out_channels, d, h, w), device=self.device, dtype=torch.float32)
         nbytes = self.workspace_bytes(d, h, w)
-        workspace = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        if workspace is None:
+            workspace = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        elif workspace.dtype != torch.uint8 or workspace.device != self.device or workspace.numel() < nbytes or not workspace.is_contiguous():
+            raise ValueError(f"workspace must be a contiguous uint8 tensor of >= {nbytes} bytes on {self.device}")
         check(self.lib.pixie_unet_forward(self._h, _ptr(feat), _ptr(proj0), d, h, w, _ptr(out), _ptr(workspace), nbytes,
                                           _lib.current_stream_ptr()), "pixie_unet_forward")
         return out
@@ -657,7 +662,8 @@ class _PixieUNet(nn.Module):
                 return out
             # second call: the same buffer again -> capture in place; another one -> capture on a private input buffer, for
             # good (at most two captures; each owns a workspace: 4 GB at 128^3, 30 GB at 256^3)
-            in_place = self._graphs["first_ptr"] == src.data_ptr() and "copy" not in self._graphs
+            in_place = (self._graphs["first_ptr"] == src.data_ptr() and "copy" not in self._graphs
+                        and os.environ.get("PIXIE_UNET_GRAPH_INPLACE", "1") == "1")
             try:
                 static_in = src if in_place else src.clone()
                 side = torch.cuda.Stream(src.device)
