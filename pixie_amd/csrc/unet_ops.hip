@@ -363,10 +363,20 @@ int channel_stats_prezeroed(const float* d_x, int channels, int64_t spatial, dou
 }
 }  // namespace pixie
 
+namespace pixie {
+__global__ void zero_doubles_kernel(double* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+}  // namespace pixie
+
 extern "C" int pixie_channel_stats(const float* d_x, int channels, int64_t spatial, double* d_sums, uint32_t* d_amax, void* stream) {
     PX_REQUIRE(d_x && d_sums && channels > 0 && spatial > 0, "pixie_channel_stats: bad arguments");
     hipStream_t st = as_stream(stream);
-    PX_CHECK_HIP(hipMemsetAsync(d_sums, 0, (size_t)channels * 2 * sizeof(double), st));
+    // cleared by a kernel: this call is captured into HIP graphs (pixie_amd/unet.py), and a hipMemsetAsync node did not reliably
+    // precede the kernels behind it on ROCm 7.2 (unet_exec.hip, profiles/r3i_graph_replay_bisect.txt)
+    hipLaunchKernelGGL(pixie::zero_doubles_kernel, dim3((unsigned)((2 * channels + 255) / 256)), dim3(256), 0, st, d_sums, 2 * channels);
+    PX_CHECK_HIP(hipGetLastError());
     return pixie::channel_stats_prezeroed(d_x, channels, spatial, d_sums, d_amax, st);
 }
 
