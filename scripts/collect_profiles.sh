@@ -3,7 +3,7 @@
 TAG=$1
 SRC=gpurun_out/$TAG
 [ -d "$SRC" ] || { echo "no $SRC"; exit 1; }
-for f in kernel_stats.csv kernel_stats_single_stream.csv prof_bench_single_stream.json bench.json prof_bench.json smoke.log device.txt pmc_traffic.json; do
+for f in kernel_stats.csv kernel_stats_by_geometry.csv mpm_trace_1m.txt mpm_trace_100k.txt kernel_stats_single_stream.csv prof_bench_single_stream.json bench.json prof_bench.json smoke.log device.txt pmc_traffic.json; do
   [ -f $SRC/$f ] && cp $SRC/$f profiles/${TAG}_$f
 done
 for f in $SRC/pmc_*.txt $SRC/*_microbench.txt $SRC/conv_winograd_bound.txt $SRC/unet_exec_bench.txt; do
