@@ -1423,7 +1423,9 @@ int rebin(pixie_mpm* h, hipStream_t st) {
             if (drift_cells > 0.0) k = (int)std::min<double>(4.0 * k, std::max<double>(0.25 * k, k * 0.4 / drift_cells));
             else k = 4 * k;
             if (since > (unsigned long long)n / 1000) k = std::min(k, h->resort_interval / 2);
-            h->resort_interval = std::max(2, std::min(k, 256));
+            // (ceiling 1024: a re-binning of 1 M particles is ~6 substeps' worth of time, so at 256 it still cost 2.6 % of a
+            // quiet scene's run; a scene that wakes up inside a long interval pays through the slow path until the next one)
+            h->resort_interval = std::max(2, std::min(k, 1024));
         }
         h->xref_valid = true;
     }
