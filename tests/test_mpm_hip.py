@@ -236,6 +236,29 @@ def test_latency_optimised_variant_matches(hip_device):
     assert rel_l2(res[1]["v"], res[0]["v"]) < 1e-4
 
 
+@pytest.mark.parametrize("bits", SCATTER_MODES)
+def test_kernel_variants_bit_identical(hip_device, bits):
+    """set_scalar "lds_pad" 0..3 changes only WHERE the tile's nodes sit in LDS (bank-conflict-free pitches) and "pk_math"
+    only whether the transfer cores' FMAs issue as packed pairs (v_pk_fma_f32) or one by one: the same operations in the
+    same order on order-independent integer sums, so every variant must return bit-identical fields.  (12 000 particles:
+    no grid block holds more than one 256-particle work item, so the binning -- whose arrival order inside a block is
+    not fixed -- cannot move a particle between work items and their scales.)"""
+    sc = mpm_ball_scene(12000, seed=8, scenario="ball")
+    res = {}
+    variants = [(0, 0), (0, 1), (1, 1), (2, 1), (3, 1), (3, 0)]
+    for pad, pk in variants:
+        h = make_hip(sc, bits=bits)
+        h._set_scalar("lds_pad", pad)
+        h._set_scalar("pk_math", pk)
+        h._set_scalar("wide", 0)
+        h.run(sc["dt"], 60)
+        res[pad, pk] = {f: get(h, f) for f in ("x", "v", "C", "F_trial")}
+        assert h.out_of_bounds == 0
+    for key in variants[1:]:
+        for f in res[0, 0]:
+            assert np.array_equal(res[key][f], res[0, 0][f]), (key, f)
+
+
 def test_packed_scatter_parity(hip_device):
     """set_scalar "scatter_bits" 32: two 32-bit fixed-point sums per LDS atomic (2 atomics per node instead of 4).  The sums
     stay exact integers (bit-reproducible), the quantum grows from 2^-42 to 2^-22 of the largest contribution bound in a
