@@ -187,8 +187,8 @@ __device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float
             float s[3] = {0, 0, 0}, d[3] = {0, 0, 0}, z[3] = {0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float4 q = fetch(i, j, k);
-                const float g[3] = {q.x, q.y, q.z};
+                float g[3];
+                fetch(i, j, k, g);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     s[a] = fmaf(wz.w[k], g[a], s[a]);
@@ -216,117 +216,6 @@ __device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float
             B.m[3 * a + 2] = fmaf(wx.w[i], sz[a], B.m[3 * a + 2]);
         }
         if (SCHED) __builtin_amdgcn_sched_barrier(0);  // keep the 27 loads of the next x-slab from being hoisted over this one
-    }
-}
-
-// ---- the same two cores on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes of arithmetic per VALU issue slot).
-// The fused kernel is VALU-issue-bound (one instruction per 4 cycles per SIMD whatever it computes), and a packed FMA
-// costs 5.7 cycles against 2 x 4.6 (profiles/r2end_valu_rate_microbench.txt).  The x and y components of every sum
-// share a register pair -- they arrive adjacent from the float4 tile -- and take one packed FMA per weight kind; the z
-// component pairs up ACROSS kinds instead ((w, dw) is a natural pair), its third kind stays scalar.  Operation for
-// operation the same FMAs as the scalar cores, so the results are bit-identical; the compiler's own SLP packing of
-// this kernel needs 168 VGPRs (build.py), this hand-packing none extra.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
-
-template <bool SCHED, class Fetch>
-__device__ __forceinline__ void g2p_gather_pk(const Stencil& st, Fetch fetch, float nv[3], Mat3& B, Mat3& G) {
-    Weights1D wx, wy, wz;
-    weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
-    v2f nvp = splat(0.f), Gp[3], Bp[3];     // (x, y) components: nv, G[.][b], B[.][b]
-    v2f nvG0 = splat(0.f);                  // z component: (nv_z, G_z0)
-    float Bz0 = 0.f, Gz1 = 0.f, Bz1 = 0.f, Gz2 = 0.f, Bz2 = 0.f;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { Gp[b] = splat(0.f); Bp[b] = splat(0.f); }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        v2f ss = splat(0.f), ds = splat(0.f), ys = splat(0.f), sd = splat(0.f), sz = splat(0.f);
-        v2f ssds_z = splat(0.f);            // z component: (ss_z, ds_z)
-        float ys_z = 0.f, sd_z = 0.f, sz_z = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            v2f sx = splat(0.f), dx = splat(0.f), zx = splat(0.f);
-            v2f sd_zc = splat(0.f);         // z component: (s_z, d_z)
-            float z_zc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 q = fetch(i, j, k);
-                const v2f gxy = v2f{q.x, q.y};
-                sx = pk_fma(splat(wz.w[k]), gxy, sx);
-                dx = pk_fma(splat(wz.dw[k]), gxy, dx);
-                zx = pk_fma(splat(wz.wd[k]), gxy, zx);
-                sd_zc = pk_fma(v2f{wz.w[k], wz.dw[k]}, splat(q.z), sd_zc);
-                z_zc = fmaf(wz.wd[k], q.z, z_zc);
-            }
-            ss = pk_fma(splat(wy.w[j]), sx, ss);
-            ds = pk_fma(splat(wy.dw[j]), sx, ds);
-            ys = pk_fma(splat(wy.wd[j]), sx, ys);
-            sd = pk_fma(splat(wy.w[j]), dx, sd);
-            sz = pk_fma(splat(wy.w[j]), zx, sz);
-            ssds_z = pk_fma(v2f{wy.w[j], wy.dw[j]}, splat(sd_zc.x), ssds_z);
-            ys_z = fmaf(wy.wd[j], sd_zc.x, ys_z);
-            sd_z = fmaf(wy.w[j], sd_zc.y, sd_z);
-            sz_z = fmaf(wy.w[j], z_zc, sz_z);
-        }
-        nvp = pk_fma(splat(wx.w[i]), ss, nvp);
-        Gp[0] = pk_fma(splat(wx.dw[i]), ss, Gp[0]);
-        Bp[0] = pk_fma(splat(wx.wd[i]), ss, Bp[0]);
-        Gp[1] = pk_fma(splat(wx.w[i]), ds, Gp[1]);
-        Bp[1] = pk_fma(splat(wx.w[i]), ys, Bp[1]);
-        Gp[2] = pk_fma(splat(wx.w[i]), sd, Gp[2]);
-        Bp[2] = pk_fma(splat(wx.w[i]), sz, Bp[2]);
-        nvG0 = pk_fma(v2f{wx.w[i], wx.dw[i]}, splat(ssds_z.x), nvG0);
-        Bz0 = fmaf(wx.wd[i], ssds_z.x, Bz0);
-        Gz1 = fmaf(wx.w[i], ssds_z.y, Gz1);
-        Bz1 = fmaf(wx.w[i], ys_z, Bz1);
-        Gz2 = fmaf(wx.w[i], sd_z, Gz2);
-        Bz2 = fmaf(wx.w[i], sz_z, Bz2);
-        if (SCHED) __builtin_amdgcn_sched_barrier(0);
-    }
-    nv[0] = nvp.x; nv[1] = nvp.y; nv[2] = nvG0.x;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { G.m[b] = Gp[b].x; G.m[3 + b] = Gp[b].y; B.m[b] = Bp[b].x; B.m[3 + b] = Bp[b].y; }
-    G.m[6] = nvG0.y; G.m[7] = Gz1; G.m[8] = Gz2;
-    B.m[6] = Bz0; B.m[7] = Bz1; B.m[8] = Bz2;
-}
-
-template <bool SCHED, class Emit>
-__device__ __forceinline__ void p2g_scatter_pk(const Stencil& st, const float mv[3], const Mat3& A, const Mat3& T, float mass, Emit emit) {
-    Weights1D wx, wy, wz;
-    weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
-    const v2f mvp = v2f{mv[0], mv[1]};
-    v2f Ap[3], Tp[3];                       // column b of A and T, rows (x, y)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { Ap[b] = v2f{A.m[b], A.m[3 + b]}; Tp[b] = v2f{T.m[b], T.m[3 + b]}; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const v2f e = pk_fma(Ap[0], splat(wx.wd[i]), splat(wx.w[i]) * mvp);
-        const v2f tx = Tp[0] * splat(wx.dw[i]);
-        const float ez = fmaf(A.m[6], wx.wd[i], wx.w[i] * mv[2]);
-        const float tz = T.m[6] * wx.dw[i];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float wij = wx.w[i] * wy.w[j];
-            const float widj = wx.w[i] * wy.dw[j];
-            const float wijd = wx.w[i] * wy.wd[j];
-            const v2f P = pk_fma(e, splat(wy.w[j]), pk_fma(Ap[1], splat(wijd), pk_fma(tx, splat(wy.w[j]), Tp[1] * splat(widj))));
-            const v2f Q = splat(wij) * Ap[2];
-            const v2f R = splat(wij) * Tp[2];
-            const float Pz = fmaf(ez, wy.w[j], fmaf(A.m[7], wijd, fmaf(tz, wy.w[j], T.m[7] * widj)));
-            const float Qz = wij * A.m[8];
-            const float Rz = wij * T.m[8];
-            const float M = wij * mass;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const v2f mxy = pk_fma(splat(wz.w[k]), P, pk_fma(splat(wz.wd[k]), Q, splat(wz.dw[k]) * R));
-                float mom[3];
-                mom[0] = mxy.x; mom[1] = mxy.y;
-                mom[2] = fmaf(wz.w[k], Pz, fmaf(wz.wd[k], Qz, wz.dw[k] * Rz));
-                emit(i, j, k, mom, wz.w[k] * M);
-            }
-        }
-        if (SCHED) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -470,7 +359,7 @@ __device__ __forceinline__ void preload_particle(const MpmPtrs& S, int p, Preloa
     }
 }
 
-template <bool DO_G2P, bool DO_P2G, bool SCHED, int VY, bool PK>
+template <bool DO_G2P, bool DO_P2G, bool SCHED>
 __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
                                                 int oz, const float4* tv, const Preload& L, ScatterIn& out) {
     out.active = false;
@@ -493,18 +382,15 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         Mat3 B, G;
         const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
         if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
-            const int b0 = (lx * kTS + ly) * VY + lz;   // (VY: the tile's row pitch, see the layout note in mpm_block_kernel)
-            auto fetch = [&](int i, int j, int k) {
+            const int b0 = (lx * kTS + ly) * kTS + lz;
+            g2p_gather<SCHED>(st, [&](int i, int j, int k, float g[3]) {
                 // One ds_read_b128 per node.  The .w lane is dead, but a 16-byte LDS read costs 4 LDS cycles per wave against
                 // 8 for the 12-byte ds_read_b96 the compiler would narrow it to (MI355X_MICROARCH.md, LDS table), and LDS
                 // and VALU time add up in this kernel (80.7 -> 78.4 us per launch at 1 M particles): keep the lane alive.
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v4f q = reinterpret_cast<const v4f*>(tv)[b0 + (i * kTS + j) * VY + k];
-                asm volatile("" : "+v"(q));   // (all four lanes defined by one 128-bit access)
-                return make_float4(q.x, q.y, q.z, q.w);
-            };
-            if (PK) g2p_gather_pk<SCHED>(st, fetch, nv, B, G);
-            else g2p_gather<SCHED>(st, fetch, nv, B, G);
+                const float4 q = tv[b0 + (i * kTS + j) * kTS + k];
+                asm volatile("" :: "v"(q.w));
+                g[0] = q.x; g[1] = q.y; g[2] = q.z;
+            }, nv, B, G);
         } else {
             atomicAdd(S.oob + 1, 1ull);
             float acc[21];
@@ -694,8 +580,6 @@ __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
 constexpr int F_TRACE = 1;    // phase stamps + the ablation switches of StepParams.trace (timing studies only)
 constexpr int F_PACK32 = 2;   // packed 32-bit scatter (above)
 constexpr int F_WIDE = 8;     // no scheduling barriers: for scenes too small to fill the chip, where latency, not issue, binds
-constexpr int F_PAD_SHIFT = 4; // bits 4-5: LDS tile pitch variant 0..3 (layout note in the kernel)
-constexpr int F_SCALAR = 64;  // the transfer cores on scalar FMAs instead of packed ones (g2p_gather_pk); A/B and fallback
 
 // OCC = waves per SIMD the register allocation is held to (launch_bounds).  Built without the SLP vectoriser (see
 // pixie_amd/build.py) the kernel needs 96 VGPRs -> 5 waves per SIMD with no spills (with it: 168 VGPRs, 3 waves, and
@@ -706,19 +590,8 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     constexpr bool PACK = (FL & F_PACK32) != 0;
     constexpr bool TRACE = (FL & F_TRACE) != 0;
     constexpr bool SCHED = (FL & F_WIDE) == 0;
-    constexpr bool PK = (FL & F_SCALAR) == 0;
-    // LDS tile layout.  Node (lx, ly, lz) of the 8^3 tile sits at  lx * 8 * pitch_y + ly * pitch_y + lz  (+ an x pitch of its
-    // own for the integer tile).  Lanes of a wave are in different CELLS of the 4^3 block (round-robin binning), so one
-    // stencil offset touches the nodes (cx, cy, cz) + const.  With the natural pitch 8 the float4 tile puts (ly, lz) and
-    // (ly + 2, lz) on the same 16-byte bank quad -- a 2-way conflict on every ds_read_b128 group -- and likewise for the
-    // 8-byte atomics; pitch 12 spreads the four ly of a group over the four quads (12 ly mod 16 = 12, 8, 4, 0).
-    //   variant 0: pitch 8 everywhere; 1: velocity tile pitch 12; 2: + integer tile pitch 12; 3: + integer x pitch 112
-    //   (= 16 mod 32: the two cx of a 32-lane half land on disjoint bank sets).
-    constexpr int PADV = (FL >> F_PAD_SHIFT) & 3;
-    constexpr int VY = PADV >= 1 ? 12 : kTS, VN = kTS * kTS * VY;
-    constexpr int AY = PADV >= 2 ? 12 : kTS, AX = PADV == 3 ? 112 : kTS * AY, AN = kTS * AX;
-    __shared__ float4 tv[VN];    // grid velocities of the tile (G2P source)
-    __shared__ unsigned long long ta[PACK ? 2 : 4][AN];  // (m*v.xyz, m) of this work item as scaled integers (P2G target)
+    __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
+    __shared__ unsigned long long ta[PACK ? 2 : 4][kTN];  // (m*v.xyz, m) of this work item as scaled integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
     const int4 it = S.items[blockIdx.x];
     const int tid = threadIdx.x;
@@ -736,14 +609,13 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng && !(TRACE && (sp.trace & 0x400)))
                 g = S.gout[((size_t)gx * ng + gy) * ng + gz];
-            tv[((idx >> 6) * kTS + ((idx >> 3) & 7)) * VY + (idx & 7)] = g;
+            tv[idx] = g;
         }
-    }
-    if (DO_P2G)
-        for (int idx = tid; idx < AN; idx += nthr) {
+        if (DO_P2G) {
             ta[0][idx] = 0ull; ta[1][idx] = 0ull;
             if (!PACK) { ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
         }
+    }
     __syncthreads();
     PX_MPM_STAMP(1);
 
@@ -755,7 +627,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     const int q = tid;
     ScatterIn in;
     in.active = false;
-    if (q < it.z) particle_phase1<DO_G2P, DO_P2G, SCHED, VY, PK>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
+    if (q < it.z) particle_phase1<DO_G2P, DO_P2G, SCHED>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
     if (!DO_P2G) return;
     PX_MPM_STAMP(2);
 
@@ -771,7 +643,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         } else {
             const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
             if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
-                b0 = lx * AX + ly * AY + lz;
+                b0 = (lx * kTS + ly) * kTS + lz;
             } else {
                 atomicAdd(S.oob + 1, 1ull);
                 float mvAT[21];
@@ -823,8 +695,8 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { in.A.m[k] *= sP; in.T.m[k] *= sP; }
-        auto emit = [&](int i, int j, int k, const float mom[3], float m) {
-            const int idx = b0 + i * AX + j * AY + k;
+        p2g_scatter<SCHED>(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
+            const int idx = b0 + (i * kTS + j) * kTS + k;
             if (TRACE && (sp.trace & 0x100)) { asm volatile("" :: "v"(mom[0]), "v"(mom[1]), "v"(mom[2]), "v"(m)); return; }
             if (PACK) {
                 // v_cvt_rpi rounds exact ties UP, and ties are common (a contribution of magnitude 2^22 is a float with one
@@ -846,9 +718,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
                 atomicAdd(&ta[2][idx], to_fixed(mom[2]));
                 atomicAdd(&ta[3][idx], to_fixed(m));
             }
-        };
-        if (PK) p2g_scatter_pk<SCHED>(st, in.mv, in.A, in.T, in.mass * sM, emit);
-        else p2g_scatter<SCHED>(st, in.mv, in.A, in.T, in.mass * sM, emit);
+        });
     }
     // where this thread's nodes go in the staged tile: fetched now, consumed behind the barrier
     const unsigned lut = (nthr == kWG) ? S.staged_lut[tid] : 0u;
@@ -860,15 +730,14 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     if (!(TRACE && (sp.trace & 0x800)))
         for (int idx = tid; idx < kTN; idx += nthr) {
             float4 o;
-            const int ai = (idx >> 6) * AX + ((idx >> 3) & 7) * AY + (idx & 7);
             if (PACK) {
                 int px, py, pm, pz;
-                unpack_pair(ta[0][ai], px, py);
-                const unsigned long long w1 = ta[1][ai];
+                unpack_pair(ta[0][idx], px, py);
+                const unsigned long long w1 = ta[1][idx];
                 pm = (int)(unsigned)w1; pz = (int)(unsigned)(w1 >> 32);
                 o = make_float4((float)px * iP, (float)py * iP, (float)pz * iP, (float)pm * iM);
             } else {
-                o = make_float4(from_fixed(ta[0][ai], iP), from_fixed(ta[1][ai], iP), from_fixed(ta[2][ai], iP), from_fixed(ta[3][ai], iM));
+                o = make_float4(from_fixed(ta[0][idx], iP), from_fixed(ta[1][idx], iP), from_fixed(ta[2][idx], iP), from_fixed(ta[3][idx], iM));
             }
             // (staged_index is ~30 instructions of selects per node; with the usual 256-thread work items each thread's two
             // nodes are tid and tid + 256 and their staged positions come from a 1 KB table, two 16-bit halves of one word)
@@ -964,6 +833,14 @@ __global__ __launch_bounds__(256) void bin_order_kernel(const int* __restrict__ 
 // the block kernel then sit in consecutive cells, so the 27 same-offset LDS accesses of a wave (G2P reads and P2G
 // ds_add_u64) hit distinct nodes in distinct banks instead of colliding 3-4 ways as they do in arrival order.
 // One workgroup per block; `order` holds the block-contiguous listing, `order2` receives the final one.
+//
+// The rank within the cell is the particle's rank by its CURRENT SLOT among the block's particles of that cell -- not
+// its arrival number (`order` is filled through atomics, so arrival differs from run to run).  That makes the listing,
+// and with it the split of a crowded block into 256-particle work items and their fixed-point scales, a pure function
+// of the particle data: together with the integer tile sums and the fixed summation order of the grid kernel, a rollout
+// is bit-reproducible from run to run (as long as no particle takes the slow path's fp32 atomics).  Counting
+// "same cell, lower slot" is quadratic in the block's population -- cnt^2 / 256 compares per thread through LDS tiles,
+// ~20 us for the 800-particle blocks of the 100 k scene, once per re-binning.
 __device__ __forceinline__ int cell_in_block(const MpmPtrs& S, int p) {
     int c = 0;
 #pragma unroll
@@ -978,6 +855,7 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
                                                               const int* __restrict__ order, int* __restrict__ cellk,
                                                               int* __restrict__ rank, int* __restrict__ order2) {
     __shared__ int cc[kBS * kBS * kBS];
+    __shared__ int2 s_tile[256];
     const int b = blockIdx.x;
     const int cnt = counts[b];
     if (cnt == 0) return;
@@ -985,20 +863,35 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
     if (threadIdx.x < kBS * kBS * kBS) cc[threadIdx.x] = 0;
     __syncthreads();
     for (int t = threadIdx.x; t < cnt; t += 256) {
-        const int p = order[off + t];
-        const int c = cell_in_block(S, p);
+        const int c = cell_in_block(S, order[off + t]);
         cellk[off + t] = c;
-        rank[off + t] = atomicAdd(&cc[c], 1);
+        atomicAdd(&cc[c], 1);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < cnt; t += 256) {
-        const int c = cellk[off + t], r = rank[off + t];
-        int pos = 0;
-        for (int k = 0; k < kBS * kBS * kBS; ++k) {
-            const int n = cc[k];
-            pos += min(n, r) + ((k < c && n > r) ? 1 : 0);
+    for (int t0 = 0; t0 < cnt; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const bool mine = t < cnt;
+        const int c = mine ? cellk[off + t] : -1, p = mine ? order[off + t] : 0;
+        int r = 0;
+        for (int u0 = 0; u0 < cnt; u0 += 256) {
+            __syncthreads();
+            const int u = u0 + threadIdx.x;
+            s_tile[threadIdx.x] = (u < cnt) ? make_int2(cellk[off + u], order[off + u]) : make_int2(-2, 0);
+            __syncthreads();
+            const int m = min(256, cnt - u0);
+            for (int k = 0; k < m; ++k) {
+                const int2 e = s_tile[k];
+                r += (e.x == c && e.y < p) ? 1 : 0;
+            }
         }
-        order2[off + pos] = order[off + t];
+        if (mine) {
+            int pos = 0;
+            for (int k = 0; k < kBS * kBS * kBS; ++k) {
+                const int n = cc[k];
+                pos += min(n, r) + ((k < c && n > r) ? 1 : 0);
+            }
+            order2[off + pos] = p;
+        }
     }
 }
 
@@ -1458,8 +1351,6 @@ struct pixie_mpm {
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
     int2* nbr_table = nullptr;               // 28 int2 per active block (see MpmPtrs)
-    int pk_math = 1;                         // transfer cores on packed fp32 (g2p_gather_pk); 0: scalar FMAs
-    int lds_pad = 0;                         // LDS tile pitch variant 0..3 (mpm_block_kernel layout note)
     int scatter_bits = 32;                   // 32 (default): packed pairs of 32-bit sums, 2 LDS atomics per node; 64: exact 64-bit fixed point, 4 per node
     int wide = -1;                           // -1 auto: the latency-optimised variant when the scene cannot fill the chip; 0/1 forced
     int n_cus = 256;
@@ -1642,24 +1533,8 @@ void launch_block(const pixie_mpm* h, dim3 grid, hipStream_t st, const StepParam
 }
 // exact (64-bit) or packed (32-bit pairs) scatter
 template <bool G, bool P, int OCC, int BASE>
-void launch_block_q(const pixie_mpm* h, bool pack, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms);
-template <bool G, bool P, int OCC, int BASE>
 void launch_block_p(const pixie_mpm* h, bool pack, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms) {
-    if (h->pk_math) launch_block_q<G, P, OCC, BASE>(h, pack, grid, st, sp, pms);
-    else launch_block_q<G, P, OCC, BASE | F_SCALAR>(h, pack, grid, st, sp, pms);
-}
-template <bool G, bool P, int OCC, int BASE>
-void launch_block_q(const pixie_mpm* h, bool pack, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms) {
-    // (the exact mode's four integer tiles leave no LDS for their padding at 5 workgroups per CU: velocity tile only)
-    const int pad = pack ? h->lds_pad : std::min(h->lds_pad, 1);
-    if (pack) {
-        switch (pad) {
-            case 0: launch_block<G, P, OCC, BASE | F_PACK32>(h, grid, st, sp, pms); break;
-            case 1: launch_block<G, P, OCC, BASE | F_PACK32 | (1 << F_PAD_SHIFT)>(h, grid, st, sp, pms); break;
-            case 2: launch_block<G, P, OCC, BASE | F_PACK32 | (2 << F_PAD_SHIFT)>(h, grid, st, sp, pms); break;
-            default: launch_block<G, P, OCC, BASE | F_PACK32 | (3 << F_PAD_SHIFT)>(h, grid, st, sp, pms); break;
-        }
-    } else if (pad) launch_block<G, P, OCC, BASE | (1 << F_PAD_SHIFT)>(h, grid, st, sp, pms);
+    if (pack) launch_block<G, P, OCC, BASE | F_PACK32>(h, grid, st, sp, pms);
     else launch_block<G, P, OCC, BASE>(h, grid, st, sp, pms);
 }
 
@@ -1701,7 +1576,6 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         if (h->trace) launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms);
         else if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
         else if (h->occupancy >= 6 && !pack) launch_block<true, true, 6, 0>(h, grid, st, sp, pms);
-        else if (h->occupancy == 4) launch_block_p<true, true, 4, 0>(h, pack, grid, st, sp, pms);
         else launch_block_p<true, true, 5, 0>(h, pack, grid, st, sp, pms);
     } else {
         if (g2p) {
@@ -1987,11 +1861,9 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
     else if (k == "scatter_bits") { PX_REQUIRE(value == 64 || value == 32, "scatter_bits must be 64 (exact) or 32 (packed pairs)"); h->scatter_bits = (int)value; }
-    else if (k == "pk_math") { PX_REQUIRE(value == 0 || value == 1, "pk_math must be 0 or 1"); h->pk_math = (int)value; }
-    else if (k == "lds_pad") { PX_REQUIRE(value >= 0 && value <= 3, "lds_pad must be 0..3"); h->lds_pad = (int)value; }
     else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
     else if (k == "trace") h->trace = (int)value;
-    else if (k == "occupancy") { PX_REQUIRE(value >= 4 && value <= 6, "occupancy must be 4, 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
+    else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
     else return set_error("set_scalar: unknown key '%s'", key);
@@ -2010,8 +1882,6 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
     else if (k == "scatter_bits") *value = h->scatter_bits;
-    else if (k == "lds_pad") *value = h->lds_pad;
-    else if (k == "pk_math") *value = h->pk_math;
     else if (k == "n_active_blocks") *value = h->n_active;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
     else if (k == "lost_particles_seen") *value = (double)h->lost_seen;   // as of the last re-binning; does not synchronise

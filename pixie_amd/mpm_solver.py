@@ -350,6 +350,8 @@ class MPM_Simulator_WARP:
             self.flush()
         self._pending_dt = dt
         self._pending += 1
+        if self.live_exports:
+            self._refresh_views()
 
     def run(self, dt, n_substeps):
         """n substeps of p2g2p in one call (fused G2P->P2G->grid launches, no host synchronisation)."""
@@ -359,6 +361,8 @@ class MPM_Simulator_WARP:
         self._pending_dt = dt
         self._pending += int(n_substeps)
         self.flush()
+        if self.live_exports:
+            self._refresh_views()
 
     @property
     def scatter_bits(self):
@@ -435,6 +439,19 @@ class MPM_Simulator_WARP:
         if t is None or t.device != self.device or tuple(t.shape) != tuple(shape):
             t = views[key] = torch.empty(shape, dtype=dtype, device=self.device)
         return t
+
+    # Opt-in emulation of the reference's live aliases: with `live_exports = True` every tensor an export_* call has
+    # handed out is refreshed after each p2g2p / run, so a caller that holds one across substeps reads current data as
+    # it does from wp.to_torch.  It costs what it says -- no deferral, one gather launch per held field per substep --
+    # which is why it is off by default: gs_simulation.py re-exports before every use (:591-600, :636-655).
+    live_exports = False
+    _EXPORTERS = {"x": "export_particle_x_to_torch", "v": "export_particle_v_to_torch", "stress": "export_particle_stress_to_torch",
+                  "F": "export_particle_F_to_torch", "C": "export_particle_C_to_torch", "R": "export_particle_R_to_torch",
+                  "cov": "export_particle_cov_to_torch"}
+
+    def _refresh_views(self):
+        for key in list(self.__dict__.get("_views", {})):
+            getattr(self, self._EXPORTERS[key])()
 
     def export_particle_x_to_torch(self):
         return self.get_field("x", out=self._export_view("x", (self.n_particles, 3)))

@@ -219,6 +219,26 @@ def test_single_step_api_equals_batched(hip_device):
     assert np.array_equal(get(e, "x"), get(f2, "x")) and abs(e.time - f2.time) < 1e-15
 
 
+@pytest.mark.parametrize("bits", SCATTER_MODES)
+def test_rollout_bit_reproducible_with_crowded_blocks(hip_device, bits):
+    """Run-to-run bit-reproducibility at the density of BASELINE configs[3] (100 k particles in a 50^3 grid: ~800 particles
+    per 4^3 block, i.e. every block is split into several 256-particle work items, each with its own fixed-point scale).
+    The split must not depend on the order in which the re-binning's atomics happened to arrive: slots inside a block are
+    ranked by (cell, previous slot).  Three re-binnings are forced inside the run."""
+    sc = mpm_ball_scene(100000, seed=12)
+    res = []
+    for rep in range(3):
+        h = make_hip(sc, bits=bits)
+        h._set_scalar("resort_interval", 40)
+        h.run(sc["dt"], 150)
+        assert int(h._get_scalar("slow_path_particles")) == 0 and h.out_of_bounds == 0
+        assert int(h._get_scalar("n_work_items")) > 400
+        res.append({f: get(h, f) for f in ("x", "v", "C", "F_trial")})
+    for rep in (1, 2):
+        for f in res[0]:
+            assert np.array_equal(res[rep][f], res[0][f]), (rep, f)
+
+
 def test_latency_optimised_variant_matches(hip_device):
     """Scenes too small to fill the chip (<= 2 work items per CU: the whole work list is resident at once and a launch lasts
     one work item's latency) run the kernel variant built without scheduling barriers and with the register budget of two
@@ -234,29 +254,6 @@ def test_latency_optimised_variant_matches(hip_device):
     for f in ("x", "F_trial"):
         assert rel_l2(res[1][f], res[0][f]) < 1e-6
     assert rel_l2(res[1]["v"], res[0]["v"]) < 1e-4
-
-
-@pytest.mark.parametrize("bits", SCATTER_MODES)
-def test_kernel_variants_bit_identical(hip_device, bits):
-    """set_scalar "lds_pad" 0..3 changes only WHERE the tile's nodes sit in LDS (bank-conflict-free pitches) and "pk_math"
-    only whether the transfer cores' FMAs issue as packed pairs (v_pk_fma_f32) or one by one: the same operations in the
-    same order on order-independent integer sums, so every variant must return bit-identical fields.  (12 000 particles:
-    no grid block holds more than one 256-particle work item, so the binning -- whose arrival order inside a block is
-    not fixed -- cannot move a particle between work items and their scales.)"""
-    sc = mpm_ball_scene(12000, seed=8, scenario="ball")
-    res = {}
-    variants = [(0, 0), (0, 1), (1, 1), (2, 1), (3, 1), (3, 0)]
-    for pad, pk in variants:
-        h = make_hip(sc, bits=bits)
-        h._set_scalar("lds_pad", pad)
-        h._set_scalar("pk_math", pk)
-        h._set_scalar("wide", 0)
-        h.run(sc["dt"], 60)
-        res[pad, pk] = {f: get(h, f) for f in ("x", "v", "C", "F_trial")}
-        assert h.out_of_bounds == 0
-    for key in variants[1:]:
-        for f in res[0, 0]:
-            assert np.array_equal(res[key][f], res[0, 0][f]), (key, f)
 
 
 def test_packed_scatter_parity(hip_device):
@@ -603,6 +600,33 @@ def test_exports_cov_and_rotation(hip_device):
     E = torch.full((5000,), 3.0e5)
     h.mpm_model.E = E  # gs_simulation.py:528 style assignment
     assert np.allclose(h.mpm_model.E.numpy(), 3.0e5)
+
+
+def test_live_exports_mode(hip_device):
+    """mpm_solver_warp.py:659-741 hand out aliases of solver memory: a tensor kept across p2g2p reads current data.  Default
+    here: a kept tensor is refreshed by the next export call (documented deviation, lets p2g2p be deferred).  Opt-in
+    `live_exports = True`: every tensor handed out is refreshed after each p2g2p -- the reference's observable behaviour."""
+    sc = mpm_ball_scene(4000, seed=3, scenario="ball")
+    live, ref = make_hip(sc), make_hip(sc)
+    live.live_exports = True
+    x_held, v_held = live.export_particle_x_to_torch(), live.export_particle_v_to_torch()
+    F_held = live.export_particle_F_to_torch()
+    for i in range(7):
+        live.p2g2p(i, sc["dt"])
+        ref.p2g2p(i, sc["dt"])
+        assert live._pending == 0            # nothing deferred in this mode
+    torch.cuda.synchronize()
+    for held, name, tol in ((x_held, "x", 1e-6), (v_held, "v", 1e-4), (F_held, "F", 1e-6)):
+        assert torch.equal(held, live.get_field(name)), name    # the kept tensors ARE the current state
+        # ... and that state is the deferred path's (single-substep launches: other schedule, same maths)
+        assert rel_l2(held.cpu().numpy(), ref.get_field(name).cpu().numpy()) < tol, name
+    # default mode: the kept tensor is stale until the next export call
+    x_kept = ref.export_particle_x_to_torch()
+    before = x_kept.clone()
+    ref.p2g2p(7, sc["dt"])
+    assert torch.equal(x_kept, before)
+    ref.export_particle_x_to_torch()
+    assert not torch.equal(x_kept, before)
 
 
 def test_undefined_material_raises(hip_device):
