@@ -662,7 +662,8 @@ class _PixieUNet(nn.Module):
                 return out
             # second call: the same buffer again -> capture in place; another one -> capture on a private input buffer, for
             # good (at most two captures; each owns a workspace: 4 GB at 128^3, 30 GB at 256^3)
-            in_place = (self._graphs["first_ptr"] == src.data_ptr() and "copy" not in self._graphs
+            # (a first-projector output handed in by the fused grid path is a fresh tensor every call: never in place)
+            in_place = (proj0 is None and self._graphs["first_ptr"] == src.data_ptr() and "copy" not in self._graphs
                         and os.environ.get("PIXIE_UNET_GRAPH_INPLACE", "1") == "1")
             try:
                 static_in = src if in_place else src.clone()
