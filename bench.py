@@ -796,6 +796,8 @@ def main():
                 m_large_alt = bench_mpm(args, rank, world, device, 1_000_000, 120, min(args.mpm_large_substeps, 500), "1m",
                                         scatter_bits=other_bits[m_large["config"]["scatter_bits"]])
             m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
+            six = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 6)
+            m_multi["six_scenes"] = {k: six[k] for k in ("value", "unit", "scenes", "us_per_substep_per_scene", "finite")}
         if not dry:
             ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
             shipped = bench_shipped_shape(args, device) if (rank == 0 and world == 1 and not args.no_shipped_shape) else None
