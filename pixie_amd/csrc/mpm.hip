@@ -62,6 +62,9 @@ struct MpmPtrs {
     float4 *gin, *gout;
     const int4* items;           // work list: (block id, first slot, count, 0)
     float4* part;                // [n_items][kTN]: (m*v.xyz, m) of each work item's tile, written by its P2G
+    unsigned long long* tile_mask;  // [n_items][8]: bit t of a tile = "node t (tile coordinates, z fastest) is not all zero"
+    int sparse_tiles;            // 1: P2G stores only the non-zero nodes of a tile and the grid kernel reads only those (masks);
+                                 // 0: whole tiles both ways (scenes too small to be bandwidth-bound: one dependent load fewer)
     const int2* blk_items;       // per block: (first work item, number of work items)
     int* blk_flags;              // per block: bit 0 = active (particles nearby), bit 1 = slow-path particles wrote into gin here
     const int* active_list;      // the active blocks
@@ -742,7 +745,16 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             // (staged_index is ~30 instructions of selects per node; with the usual 256-thread work items each thread's two
             // nodes are tid and tid + 256 and their staged positions come from a 1 KB table, two 16-bit halves of one word)
             const int si = (nthr == kWG) ? (int)((idx < kWG) ? (lut & 0xffffu) : (lut >> 16)) : staged_index(idx >> 6, (idx >> 3) & 7, idx & 7);
-            dst[si] = o;
+            // Typically 40-60 % of a tile's nodes received nothing (the drift margin planes, corners beyond every stencil): they
+            // are neither stored nor -- by the mask -- read back.  Adding an all-zero float4 is a no-op, so the sums are unchanged.
+            const bool nz = (o.x != 0.0f) | (o.y != 0.0f) | (o.z != 0.0f) | (o.w != 0.0f);
+            if (S.sparse_tiles) {
+                const unsigned long long live = __ballot(nz);     // lanes of a wave hold 64 consecutive nodes
+                if ((tid & 63) == 0) S.tile_mask[(size_t)blockIdx.x * 8 + (idx >> 6)] = live;
+                if (nz) dst[si] = o;
+            } else {
+                dst[si] = o;
+            }
         }
     PX_MPM_STAMP(5);
     if (TRACE && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
@@ -1010,8 +1022,8 @@ __device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By
 template <int RB>
 __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
     const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
-    unsigned off[8];   // in float4 units from S.part
-    int cnt[8];
+    unsigned off[8];   // in float4 units from S.part: first item * kTN + staged position of this node in that block's tiles
+    int cb[8];         // items of the candidate block << 16 | this node's number in the tile (mask bit)
     int maxc = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -1020,17 +1032,33 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
         const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
         const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;  // this node inside that block's tile
         off[c] = (unsigned)first * kTN + (unsigned)staged_index(tx, ty, tz);
-        cnt[c] = n;
+        cb[c] = (n << 16) | ((tx * kTS + ty) * kTS + tz);
         maxc = max(maxc, n);
     }
     // up to RB items per block in one go: all 8 x RB tile loads of a node are issued before the first is consumed
     for (int r0 = 0; r0 < maxc; r0 += RB) {
         float4 q[RB][8];
+        unsigned live = 0xffffffffu;     // bit r * 8 + c: the node is present in that tile
+        if (S.sparse_tiles) {            // (uniform) all 8 x RB mask words first, then only the tile loads that find something
+            unsigned long long w[RB][8];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int bit = cb[c] & 0xffff;
+                    w[r][c] = (r0 + r < (cb[c] >> 16)) ? S.tile_mask[(size_t)((off[c] >> 9) + r0 + r) * 8 + (bit >> 6)] : 0ull;
+                }
+            live = 0u;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) live |= (unsigned)((w[r][c] >> (cb[c] & 63)) & 1ull) << (r * 8 + c);
+        }
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const bool on = r0 + r < cnt[c];
+                const bool on = (r0 + r < (cb[c] >> 16)) && ((live >> (r * 8 + c)) & 1u);
                 const unsigned o = off[c] + (unsigned)(r0 + r) * kTN;
                 q[r][c] = on ? S.part[o] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -1091,9 +1119,16 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
 // Only active blocks are read by the next G2P (a tile reaches one block beyond its own), so inactive blocks are skipped
 // entirely (mode 0); their grid_v_out is brought up to date on demand (mode 1, used by the grid_v_out export) with the
 // parameters of the last update, which for a massless node is just the BCs on v = 0.
+// RB (tile loads in flight per candidate block) against occupancy.  The kernel is latency-bound -- a wave is three or four
+// dependent memory round trips -- so what counts is how many waves are resident: a scene with several work items per block
+// that fits in one round of waves (100 k particles in 50^3: 2200 active blocks) wants RB = 4 (189 VGPRs, 2 waves per SIMD); a
+// scene with ~1.2 items per block and 9000 active blocks (1 M in 120^3) wants the registers back: RB = 1 = 101 VGPRs = 4 waves
+// per SIMD, 14.9 -> 12.5 us per launch together with the sparse tiles.  (Holding the allocation to 80 / 64 VGPRs for 6 / 8 waves
+// spills 22 / 39 dwords: 20.4 / 25.5 us.  profiles/r3s_mpm_grid_kernel_occupancy.txt)
+template <int RB>
 __global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
     if (mode == 0) {
-        grid_block_update<4>(S, sp, bcs, (int)blockIdx.x, S.gout);
+        grid_block_update<RB>(S, sp, bcs, (int)blockIdx.x, S.gout);
         return;
     }
     const int blk = (int)blockIdx.x;
@@ -1347,6 +1382,9 @@ struct pixie_mpm {
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
     bool pmods_were_active = false;
     float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
+    unsigned long long* tile_mask = nullptr; // [max_items][8] occupancy bits of the staged tiles
+    int grid_rb = 0;                         // grid kernel: tile loads in flight per candidate block (0 = by scene size; 1, 2, 4)
+    int sparse = -1;                         // sparse tile publishing: -1 auto (on when the work list exceeds two items per CU), 0, 1
     bool pending_p2g = false;                // staged tiles not yet consumed by the grid kernel
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
@@ -1389,7 +1427,7 @@ void bind_rows(pixie_mpm* h) {
     S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
     S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n;
-    S.items = h->items; S.part = h->part; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
+    S.items = h->items; S.part = h->part; S.tile_mask = h->tile_mask; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -1429,6 +1467,8 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
+    // (decided here and only here: never between a P2G and the grid kernel that consumes its tiles)
+    S.sparse_tiles = h->sparse >= 0 ? h->sparse : (h->n_items > 2 * h->n_cus ? 1 : 0);
     // Cadence: the LDS tile tolerates one cell of drift, and the measured drift of the interval just finished
     // predicts the next one -- aim at 0.4 cells, never more than four times the last interval (a re-binning of 1 M
     // particles costs ~0.4 ms = 4 substeps: with doubling, the ramp 4, 8, ..., 256 of a quiet scene spent six of them in
@@ -1599,6 +1639,15 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
     return 0;
 }
 
+void launch_grid_blocks(const pixie_mpm* h, hipStream_t st, const StepParams& sp, const BCSet& set, int mode, int n_wg) {
+    // auto: the same size rule as the sparse tiles and the wide block kernel (more than two work items per CU = the chip is full)
+    const int rb = h->grid_rb > 0 ? h->grid_rb : (h->n_items > 2 * h->n_cus ? 1 : 4);
+    const dim3 g((unsigned)n_wg), b(64);
+    if (rb == 1) hipLaunchKernelGGL(mpm_grid_block_kernel<1>, g, b, 0, st, h->S, sp, set, mode);
+    else if (rb == 2) hipLaunchKernelGGL(mpm_grid_block_kernel<2>, g, b, 0, st, h->S, sp, set, mode);
+    else hipLaunchKernelGGL(mpm_grid_block_kernel<4>, g, b, 0, st, h->S, sp, set, mode);
+}
+
 int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
     const long total = (long)h->S.ng * h->S.ng * h->S.ng;
     const int blocks = cdiv(total, 256);
@@ -1614,13 +1663,13 @@ int launch_grid(pixie_mpm* h, const StepParams& sp, double dt, hipStream_t st) {
         const BCSet set = make_bcset(h, done);
         if (normalise && h->pending_p2g && nbc <= (size_t)kMaxBCPerLaunch) {
             // staged tiles of the last P2G + slow-path atomics in gin; blocks with nothing nearby are skipped
-            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)std::max(h->n_active, 1)), dim3(64), 0, st, h->S, sp, set, 0);
+            launch_grid_blocks(h, st, sp, set, 0, std::max(h->n_active, 1));
             h->gout_sparse = true;
             h->last_grid_sp = sp;
             h->last_grid_bcs.assign(h->bcs_dev.begin(), h->bcs_dev.end());
         } else if (normalise && h->pending_p2g) {  // more BCs than one launch carries: dense follow-up passes need every block
-            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)std::max(h->n_active, 1)), dim3(64), 0, st, h->S, sp, set, 0);
-            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, sp, set, 1);
+            launch_grid_blocks(h, st, sp, set, 0, std::max(h->n_active, 1));
+            launch_grid_blocks(h, st, sp, set, 1, h->nblocks);
             h->gout_sparse = false;
         } else {                          // nothing staged (or a further pass of BCs over gout)
             hipLaunchKernelGGL(mpm_grid_kernel, dim3(blocks), dim3(256), 0, st, h->S, sp, set, normalise);
@@ -1653,6 +1702,7 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     std::vector<void*> old;
     old.swap(h->grid_allocs);
     float4 *gin = nullptr, *gout = nullptr, *part = nullptr;
+    unsigned long long* tile_mask = nullptr;
     int *counts = nullptr, *offsets = nullptr, *active_list = nullptr, *blk_flags = nullptr;
     int4* items = nullptr;
     int2 *nbr_table = nullptr, *blk_items = nullptr;
@@ -1664,6 +1714,7 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     rc |= dev_alloc(h, &nbr_table, (size_t)nblocks * 28, true);
     rc |= dev_alloc(h, &blk_items, (size_t)nblocks, true); rc |= dev_alloc(h, &blk_flags, (size_t)nblocks, true);
     rc |= dev_alloc(h, &part, max_items * kTN, true);
+    rc |= dev_alloc(h, &tile_mask, max_items * 8, true);
     if (rc) {   // keep the old grid
         for (void* p : h->grid_allocs) (void)hipFree(p);
         h->grid_allocs.swap(old);
@@ -1678,7 +1729,7 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     h->nblocks = nblocks;
     S.gin = gin; S.gout = gout;
     h->counts = counts; h->offsets = offsets; h->items = items; h->active_list = active_list; h->nbr_table = nbr_table;
-    h->blk_items = blk_items; h->blk_flags = blk_flags; h->part = part;
+    h->blk_items = blk_items; h->blk_flags = blk_flags; h->part = part; h->tile_mask = tile_mask;
     h->n_items = 0; h->n_active = 0;
     h->needs_sort = true; h->xref_valid = false;
     h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false;
@@ -1695,6 +1746,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     pixie_mpm* h = new pixie_mpm();
     MpmPtrs& S = h->S;
     S.n = n_particles;
+    if (const char* e = getenv("PIXIE_MPM_SPARSE_TILES")) h->sparse = atoi(e) > 0 ? 1 : (atoi(e) < 0 ? -1 : 0);   // test hook: force the mode
     const size_t n = (size_t)n_particles;
     int rc = 0;
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
@@ -1797,7 +1849,7 @@ int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t cou
             BCSet set{};
             set.n = (int)h->last_grid_bcs.size();
             for (int k = 0; k < set.n; ++k) set.bc[k] = h->last_grid_bcs[k];
-            hipLaunchKernelGGL(mpm_grid_block_kernel, dim3((unsigned)h->nblocks), dim3(64), 0, st, h->S, h->last_grid_sp, set, 1);
+            launch_grid_blocks(h, st, h->last_grid_sp, set, 1, h->nblocks);
             h->gout_sparse = false;
         }
         if (nm != "grid_v_out" && h->pending_p2g)
@@ -1861,6 +1913,8 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
     else if (k == "scatter_bits") { PX_REQUIRE(value == 64 || value == 32, "scatter_bits must be 64 (exact) or 32 (packed pairs)"); h->scatter_bits = (int)value; }
+    else if (k == "grid_rb") { PX_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "grid_rb must be 0, 1, 2 or 4"); h->grid_rb = (int)value; }
+    else if (k == "sparse_tiles") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "sparse_tiles must be -1 (auto), 0 or 1"); h->sparse = (int)value; h->needs_sort = true; }
     else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
     else if (k == "trace") h->trace = (int)value;
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }

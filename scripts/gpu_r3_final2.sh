@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 closing session on the final tree (PMC passes: profiles/r3end_pmc_*, kernels unchanged since): the whole GPU suite,
 # smoke, the driver's bench command, the same command under rocprofv3 --stats.
-OUT=gpurun_out/r3fin
+OUT=gpurun_out/${1:-r3fin}
 mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 ROOT=$(pwd)

@@ -239,6 +239,34 @@ def test_rollout_bit_reproducible_with_crowded_blocks(hip_device, bits):
             assert np.array_equal(res[rep][f], res[0][f]), (rep, f)
 
 
+@pytest.mark.parametrize("bits", SCATTER_MODES)
+def test_sparse_tile_publishing_bit_identical(hip_device, bits):
+    """set_scalar "sparse_tiles": P2G stores only the non-zero nodes of a work item's 8^3 tile plus a 512-bit occupancy mask, the
+    grid kernel reads only those (on automatically for scenes that fill the chip, together with the grid kernel's
+    high-occupancy instantiation, "grid_rb" 1).  Skipping all-zero addends cannot change a
+    sum: particle fields, the grid read back while a P2G is pending, and the updated grid must all be bit-identical."""
+    sc = mpm_ball_scene(12000, seed=21)
+    res = {}
+    variants = [(0, 4), (1, 4), (1, 1), (0, 1), (1, 2)]   # (sparse tiles, grid kernel's loads in flight per candidate block)
+    for sparse, rb in variants:
+        h = make_hip(sc, bits=bits)
+        h._set_scalar("sparse_tiles", sparse)
+        h._set_scalar("grid_rb", rb)
+        h.run(sc["dt"], 40)
+        out = {f: get(h, f) for f in ("x", "v", "C", "F_trial")}
+        h.phase(0, sc["dt"])                                   # a P2G whose tiles are still staged
+        out["grid_m"] = h.get_field("grid_m").cpu().numpy()
+        out["grid_v_in"] = h.get_field("grid_v_in").cpu().numpy()
+        h.phase(1, sc["dt"])
+        out["grid_v_out"] = h.get_field("grid_v_out").cpu().numpy()
+        assert h.out_of_bounds == 0
+        res[sparse, rb] = out
+    assert float(np.abs(res[0, 4]["grid_m"]).sum()) > 0
+    for key in variants[1:]:
+        for f in res[0, 4]:
+            assert np.array_equal(res[key][f], res[0, 4][f]), (key, f)
+
+
 def test_latency_optimised_variant_matches(hip_device):
     """Scenes too small to fill the chip (<= 2 work items per CU: the whole work list is resident at once and a launch lasts
     one work item's latency) run the kernel variant built without scheduling barriers and with the register budget of two
