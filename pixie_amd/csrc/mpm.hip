@@ -1417,6 +1417,12 @@ int dev_alloc(pixie_mpm* h, T** ptr, size_t count, bool grid_sized = false) {
     return 0;
 }
 
+// The grid kernel runs one wave per active block.  Its RB = 4 instantiation fits two waves per SIMD: with more active blocks
+// than that (1 M particles in 120^3: ~2600 on 2048 slots) the launch takes a second round of waves and the leaner RB = 1
+// instantiation + sparse tiles win (14.9 -> 12.5 us); below it (100 k in 50^3: ~520) a launch is one wave's latency and the
+// fewer dependent loads the better (whole tiles, RB = 4: 18.7 vs 20.9 us per substep).
+bool grid_kernel_crowded(const pixie_mpm* h) { return h->n_active > 8 * h->n_cus; }
+
 // point the row pointers of h->S at the current copy of the word array
 void bind_rows(pixie_mpm* h) {
     MpmPtrs& S = h->S;
@@ -1468,7 +1474,7 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
     // (decided here and only here: never between a P2G and the grid kernel that consumes its tiles)
-    S.sparse_tiles = h->sparse >= 0 ? h->sparse : (h->n_items > 2 * h->n_cus ? 1 : 0);
+    S.sparse_tiles = h->sparse >= 0 ? h->sparse : (grid_kernel_crowded(h) ? 1 : 0);
     // Cadence: the LDS tile tolerates one cell of drift, and the measured drift of the interval just finished
     // predicts the next one -- aim at 0.4 cells, never more than four times the last interval (a re-binning of 1 M
     // particles costs ~0.4 ms = 4 substeps: with doubling, the ramp 4, 8, ..., 256 of a quiet scene spent six of them in
@@ -1640,8 +1646,7 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
 }
 
 void launch_grid_blocks(const pixie_mpm* h, hipStream_t st, const StepParams& sp, const BCSet& set, int mode, int n_wg) {
-    // auto: the same size rule as the sparse tiles and the wide block kernel (more than two work items per CU = the chip is full)
-    const int rb = h->grid_rb > 0 ? h->grid_rb : (h->n_items > 2 * h->n_cus ? 1 : 4);
+    const int rb = h->grid_rb > 0 ? h->grid_rb : (grid_kernel_crowded(h) ? 1 : 4);
     const dim3 g((unsigned)n_wg), b(64);
     if (rb == 1) hipLaunchKernelGGL(mpm_grid_block_kernel<1>, g, b, 0, st, h->S, sp, set, mode);
     else if (rb == 2) hipLaunchKernelGGL(mpm_grid_block_kernel<2>, g, b, 0, st, h->S, sp, set, mode);
