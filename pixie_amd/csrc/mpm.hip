@@ -1035,37 +1035,45 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
         cb[c] = (n << 16) | ((tx * kTS + ty) * kTS + tz);
         maxc = max(maxc, n);
     }
-    // up to RB items per block in one go: all 8 x RB tile loads of a node are issued before the first is consumed
-    for (int r0 = 0; r0 < maxc; r0 += RB) {
-        float4 q[RB][8];
-        unsigned live = 0xffffffffu;     // bit r * 8 + c: the node is present in that tile
-        if (S.sparse_tiles) {            // (uniform) all 8 x RB mask words first, then only the tile loads that find something
-            unsigned long long w[RB][8];
+    // Eight rounds (items per candidate block) at a time.  Sparse tiles: first ALL mask words of these rounds (4 x 8 in flight,
+    // reduced to one bit each), then the tile loads that find something, RB rounds = 8 x RB loads in flight -- so a node covered
+    // by three items per block costs one round trip for the masks and ceil(3 / RB) for the tiles, not two per item.
+    // The order of the sum is (round, candidate) whatever RB: every instantiation returns the same bits.
+    for (int r0 = 0; r0 < maxc; r0 += 8) {
+        unsigned long long live = ~0ull;     // bit r * 8 + c: the node is present in the tile of round r0 + r, candidate c
+        if (S.sparse_tiles) {                // (uniform)
+            live = 0ull;
+            for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += 4) {
+                const unsigned* mask32 = reinterpret_cast<const unsigned*>(S.tile_mask);   // (little-endian halves of the 64-bit words)
+                unsigned w[4][8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int item = r0 + r1 + r;
+                        w[r][c] = (item < (cb[c] >> 16)) ? mask32[(size_t)((off[c] >> 9) + item) * 16 + ((cb[c] & 0xffff) >> 5)] : 0u;
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) live |= (unsigned long long)((w[r][c] >> (cb[c] & 31)) & 1u) << ((r1 + r) * 8 + c);
+            }
+        }
+        for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += RB) {
+            float4 q[RB][8];
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const int bit = cb[c] & 0xffff;
-                    w[r][c] = (r0 + r < (cb[c] >> 16)) ? S.tile_mask[(size_t)((off[c] >> 9) + r0 + r) * 8 + (bit >> 6)] : 0ull;
+                    const int item = r0 + r1 + r;
+                    const bool on = (item < (cb[c] >> 16)) && ((live >> ((r1 + r) * 8 + c)) & 1ull);
+                    q[r][c] = on ? S.part[off[c] + (unsigned)item * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            live = 0u;
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) live |= (unsigned)((w[r][c] >> (cb[c] & 63)) & 1ull) << (r * 8 + c);
+                for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
         }
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const bool on = (r0 + r < (cb[c] >> 16)) && ((live >> (r * 8 + c)) & 1u);
-                const unsigned o = off[c] + (unsigned)(r0 + r) * kTN;
-                q[r][c] = on ? S.part[o] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
     }
     return acc;
 }
@@ -1751,7 +1759,6 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     pixie_mpm* h = new pixie_mpm();
     MpmPtrs& S = h->S;
     S.n = n_particles;
-    if (const char* e = getenv("PIXIE_MPM_SPARSE_TILES")) h->sparse = atoi(e) > 0 ? 1 : (atoi(e) < 0 ? -1 : 0);   // test hook: force the mode
     const size_t n = (size_t)n_particles;
     int rc = 0;
     rc |= dev_alloc(h, &h->words[0], (size_t)R_COUNT * n); rc |= dev_alloc(h, &h->words[1], (size_t)R_COUNT * n);
