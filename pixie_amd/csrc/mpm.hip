@@ -1620,7 +1620,9 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
     // Latency-optimised variant (no scheduling barriers, register budget of 2 waves per SIMD): when the whole work list is
     // resident at once with room to spare (<= 2 work items per CU) nothing is gained from occupancy and the launch lasts
     // one work item's latency.
-    const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 2 * h->n_cus);
+    // (the wide instantiation needs 130 VGPRs = three waves per SIMD = three 256-thread work items per CU at once: up to that many
+    // the whole work list is resident in one round and a launch lasts one work item's latency)
+    const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 3 * h->n_cus);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile && p2g && g2p) {
         PX_CHECK_HIP(hipEventCreate(&e0)); PX_CHECK_HIP(hipEventCreate(&e1));
