@@ -43,6 +43,7 @@ namespace pixie {
 constexpr int kBS = 4;                    // cells per block edge (particles are binned by the block of their stencil base)
 constexpr int kTS = 8;                    // tile nodes per edge: kBS + 2 (stencil reach) + 2 (one-cell drift margin each side)
 constexpr int kTN = kTS * kTS * kTS;      // 512 nodes
+static_assert(kTN == 512 && kTS == 8, "gather_node recovers the work item from a tile offset with >> 9 and packs tile coordinates in 3 bits");
 constexpr int kWG = 256;                  // particles per work item / threads per workgroup (upper value)
 
 // rows of the particle word array
