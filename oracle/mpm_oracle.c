@@ -6,13 +6,15 @@
  * product) may link, import or execute this file; only tests/, bench.py's
  * cpu_baseline leg and __graft_entry__.smoke() use it, and only as the checker.
  *
- * PARITY UNPINNED for this half: the reference ships no golden vectors for the
- * solver and Warp (warp_lang==0.10.1, reference setup.py:19) cannot run in the
- * build container, so this restatement is anchored on the reference's kernel
- * sources line by line and on analytic known-answer tests (tests/test_mpm_oracle.py).
- * `wp.svd3` lives in Warp itself (not in the reference tree); it is replaced here by
- * a float64 one-sided Jacobi SVD canonicalised to Warp's documented convention
- * (U, V proper rotations, sign carried by the last singular value).
+ * PINNED to the reference's own code (round 4): tests/golden/mpm_ref_golden.npz holds rollouts computed by the
+ * reference's mpm_solver_warp.py / mpm_utils.py / warp_utils.py themselves, imported unmodified on a numpy
+ * interpreter of the Warp API subset they use (tests/golden/wp_shim, tests/golden/make_mpm_ref_golden.py): all
+ * material ids, every BC type, every particle modifier, APIC / RPIC / PIC, inverted elements.  The float64 build of
+ * this file reproduces every particle and grid field of those runs to <= 2e-14 (tests/test_mpm_ref_golden.py).
+ * What stays a stand-in on BOTH sides is `wp.svd3`: it lives in Warp's native library (warp_lang==0.10.1, reference
+ * setup.py:19), not in the reference tree.  Here: a float64 one-sided Jacobi SVD canonicalised to the convention of
+ * Warp's implementation (U, V proper rotations, sign carried by the last singular value); the fixture uses LAPACK
+ * canonicalised the same way and also records what LAPACK's own convention would give for det F < 0.
  *
  * Every function cites the reference lines it follows.  Paths are relative to
  * /root/reference/third_party/PhysGaussian/mpm_solver_warp/.
@@ -306,6 +308,14 @@ typedef struct {
 #define GI(s, ix, iy, iz) ((((size_t)(ix)) * (s)->ng + (iy)) * (s)->ng + (iz))
 
 /* MPM_Simulator_WARP.initialize, mpm_solver_warp.py:52-180 */
+/* mpm_solver_warp.py:84-86, 391-393: `wp.sin` / `wp.sqrt` called from Python scope run Warp's float32 built-ins
+ * (float32 argument and result), the products around them are Python doubles, the struct member is a float32.  The
+ * last bit of sinf is the host libm's; tests/golden/mpm_ref_golden.npz records the value numpy's float32 sin gives. */
+static real host_alpha(double friction_angle) {
+    double sin_phi = (double)sinf((float)(friction_angle / 180.0 * 3.14159265));
+    return P_(((double)sqrtf((float)(2.0 / 3.0)) * 2.0 * sin_phi / (3.0 - sin_phi)));
+}
+
 MPM *mpm_create(int n, int n_grid, double grid_lim) {
     MPM *s = (MPM *)calloc(1, sizeof(MPM));
     s->n = n; s->ng = n_grid;
@@ -323,8 +333,7 @@ MPM *mpm_create(int n, int n_grid, double grid_lim) {
     s->grid_m = calloc(G, sizeof(real)); s->grid_v_in = calloc(3 * G, sizeof(real)); s->grid_v_out = calloc(3 * G, sizeof(real));
     for (size_t p = 0; p < N; ++p) { s->F_trial[9 * p] = 1; s->F_trial[9 * p + 4] = 1; s->F_trial[9 * p + 8] = 1; } /* :272-277 */
     s->rpic_damping = 0; s->grid_v_damping_scale = R_(1.1); s->softening = R_(0.1); /* :79-92 */
-    double sin_phi = sin(25.0 / 180.0 * 3.14159265);                                  /* :84-86 */
-    s->alpha = P_((sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi)));
+    s->alpha = host_alpha(25.0);                                                      /* :84-86 */
     s->time = 0.0;
     return s;
 }
@@ -367,10 +376,8 @@ void mpm_set_scalar(MPM *s, const char *name, double val) {
     else if (!strcmp(name, "gy")) s->g[1] = P_(val);
     else if (!strcmp(name, "gz")) s->g[2] = P_(val);
     else if (!strcmp(name, "time")) s->time = val;
-    else if (!strcmp(name, "friction_angle")) { /* mpm_solver_warp.py:390-393 */
-        double sin_phi = sin(val / 180.0 * 3.14159265);
-        s->alpha = P_((sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi)));
-    }
+    else if (!strcmp(name, "friction_angle")) s->alpha = host_alpha(val); /* mpm_solver_warp.py:390-393 */
+    else if (!strcmp(name, "alpha")) s->alpha = P_(val);                  /* test hook: the value a fixture recorded */
 }
 double mpm_get_time(MPM *s) { return s->time; }
 long mpm_get_oob(MPM *s) { return s->oob; }

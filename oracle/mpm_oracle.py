@@ -6,7 +6,7 @@ module, and only as the checker.  pixie_amd/ never does.
 `OracleMPM` mirrors the call surface of the reference's `MPM_Simulator_WARP`
 (/root/reference/third_party/PhysGaussian/mpm_solver_warp/mpm_solver_warp.py:47-1210)
 closely enough that a parity test drives the oracle and the HIP solver with the same
-script.  PARITY UNPINNED (see mpm_oracle.c header): no golden vectors exist upstream.
+script.  Pinned to the reference's own solver code by tests/test_mpm_ref_golden.py (see mpm_oracle.c header).
 """
 from __future__ import annotations
 
@@ -154,7 +154,8 @@ class OracleMPM:
         for key, fld in (("E", "E"), ("nu", "nu"), ("bulk_modulus", "bulk"), ("yield_stress", "yield_stress")):
             if key in kwargs:
                 self.field(fld)[:] = np.float32(kwargs[key])   # the reference fills a float32 array (warp_utils.py:222-230)
-        for key in ("hardening", "xi", "friction_angle", "rpic_damping", "plastic_viscosity", "softening", "grid_v_damping_scale"):
+        for key in ("hardening", "xi", "friction_angle", "rpic_damping", "plastic_viscosity", "softening", "grid_v_damping_scale",
+                    "alpha"):
             if key in kwargs:
                 self._lib.mpm_set_scalar(self._h, key.encode(), float(kwargs[key]))
         if "g" in kwargs:
@@ -213,6 +214,25 @@ class OracleMPM:
         self._lib.mpm_enforce_rotation(self._h, _d3(point), _d3(normal), _d3(h1), _d3(h2), float(half_height_and_radius[0]),
                                        float(half_height_and_radius[1]), float(rotation_scale), float(translation_scale),
                                        float(start_time), float(end_time))
+
+    def release_particles_sequentially(self, normal, start_position, end_position, num_layers, start_time, end_time):
+        """mpm_solver_warp.py:1185-1210 (host logic only: 50 nested velocity pins with staggered end times; the
+        reference overrides the caller's num_layers with 50)."""
+        num_layers = 50
+        point, size, axis = [0, 0, 0], [0, 0, 0], -1
+        for i in range(3):
+            if normal[i] == 0:
+                point[i] = 1
+                size[i] = 1
+            else:
+                axis = i
+                point[i] = end_position
+        half_length_portion = abs(start_position - end_position) / num_layers
+        end_time_portion = end_time / num_layers
+        for i in range(num_layers):
+            size[axis] = half_length_portion * (num_layers - i)
+            self.enforce_particle_velocity_translation(point=point, size=size, velocity=[0, 0, 0], start_time=start_time,
+                                                       end_time=end_time_portion * (i + 1))
 
     # -- stepping --
     def p2g2p(self, step, dt):

@@ -1757,6 +1757,13 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
 
 extern "C" {
 
+// mpm_solver_warp.py:84-86, 391-393: the reference evaluates `wp.sin` / `wp.sqrt` from Python scope, i.e. Warp's float32
+// built-ins (float32 argument and result); the products around them are Python doubles and the struct member is float32.
+static float host_alpha(double friction_angle) {
+    const double sin_phi = (double)sinf((float)(friction_angle / 180.0 * 3.14159265));
+    return (float)((double)sqrtf((float)(2.0 / 3.0)) * 2.0 * sin_phi / (3.0 - sin_phi));
+}
+
 int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_lim) {
     PX_REQUIRE(out && n_particles > 0 && n_grid >= 4 && grid_lim > 0, "pixie_mpm_create: bad arguments");
     pixie_mpm* h = new pixie_mpm();
@@ -1795,8 +1802,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     PX_CHECK_HIP(hipDeviceSynchronize());
     // defaults of initialize(), mpm_solver_warp.py:74-92
     h->ms.plastic_viscosity = 0.0f; h->ms.softening = 0.1f; h->ms.hardening = 0.0f; h->ms.xi = 0.0f;
-    const double sin_phi = sin(25.0 / 180.0 * 3.14159265);
-    h->ms.alpha = (float)(sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi));
+    h->ms.alpha = host_alpha(25.0);
     h->rpic = 0.0f; h->damping = 1.1f;
     *out = h;
     return 0;
@@ -1919,10 +1925,8 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "xi") h->ms.xi = (float)value;
     else if (k == "softening") h->ms.softening = (float)value;
     else if (k == "plastic_viscosity") h->ms.plastic_viscosity = (float)value;
-    else if (k == "friction_angle") {  // mpm_solver_warp.py:390-393
-        const double sin_phi = sin(value / 180.0 * 3.14159265);
-        h->ms.alpha = (float)(sqrt(2.0 / 3.0) * 2.0 * sin_phi / (3.0 - sin_phi));
-    } else if (k == "gx") h->g[0] = (float)value;
+    else if (k == "friction_angle") h->ms.alpha = host_alpha(value);  // mpm_solver_warp.py:390-393
+    else if (k == "gx") h->g[0] = (float)value;
     else if (k == "gy") h->g[1] = (float)value;
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;

@@ -713,31 +713,29 @@ def test_full_size_sand_config(hip_device):
 
 
 def test_export_frame_for_rendering(hip_device):
-    """gs_simulation.py:591-600: positions / covariances of the first gs_num particles back in the scene frame, in one
-    launch, against a float64 restatement of transformation_utils.py:19-20,108-130 applied to the solver's own exports."""
-    sc = mpm_ball_scene(6000, seed=13, scenario="ball")
-    h = make_hip(sc)
-    h.run(sc["dt"], 25)
-    gs_num, scale, z_shift = 5000, 0.37, 0.05
-    mean = np.array([0.3, -1.2, 2.0])
-    def rot(deg, axis):
-        c, s_ = np.cos(deg / 180.0 * 3.1415926), np.sin(deg / 180.0 * 3.1415926)
-        return {0: np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]), 1: np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]),
-                2: np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])}[axis]
-    Rs = [rot(30.0, 0), rot(-75.0, 2), rot(12.0, 1)]
-    pos, cov = h.export_frame_for_rendering(gs_num, scale, torch.tensor(mean), [torch.tensor(R) for R in Rs], z_shift_value=z_shift)
-    x = get(h, "x").astype(np.float64)[:gs_num]
-    c6 = h.export_particle_cov_to_torch().cpu().numpy().reshape(-1, 6).astype(np.float64)[:gs_num]
-    p = mean + (x - np.array([1.0, 1.0, 1.0 + z_shift])) / scale          # undoshift2center111 + undotransform2origin
-    for R in reversed(Rs):                                                 # apply_inverse_rotations
-        p = p @ R
-    C = np.zeros((gs_num, 3, 3))
-    C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2] = (c6[:, k] for k in range(6))
-    C[:, 1, 0], C[:, 2, 0], C[:, 2, 1] = C[:, 0, 1], C[:, 0, 2], C[:, 1, 2]
-    C = C / scale ** 2
-    for R in reversed(Rs):                                                 # apply_inverse_cov_rotations: R^T C R
-        C = R.T @ C @ R
-    ref6 = np.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1)
-    assert pos.shape == (gs_num, 3) and cov.shape == (gs_num, 6)
-    assert rel_l2(pos.cpu().numpy(), p) < 1e-6
-    assert rel_l2(cov.cpu().numpy(), ref6) < 1e-5
+    """gs_simulation.py:591-600 in one launch, against tests/golden/frame_export.npz: the REFERENCE's own
+    transformation_utils.py / material_field.py:81-86 functions (executed via `ast`, tests/golden/make_frame_export_golden.py)
+    applied to the positions and the `compute_cov_from_F` covariances the reference's solver code produced for scene
+    `jelly_apic` of mpm_ref_golden.npz.  The product solver is put into that scene's final state (x, F_trial, init_cov)."""
+    import os
+    from tests._mpm_ref_driver import load_fixture
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, "frame_export.npz"))
+    scene, arrays, ref = load_fixture(os.path.join(here, "mpm_ref_golden.npz"))["jelly_apic"]
+    from pixie_amd.mpm_solver import MPM_Simulator_WARP
+    h = MPM_Simulator_WARP(10)
+    h.load_initial_data_from_torch(torch.from_numpy(arrays["x0"]), torch.from_numpy(arrays["vol"]), torch.from_numpy(arrays["cov"]),
+                                   n_grid=scene["n_grid"], grid_lim=scene["grid_lim"])
+    h.set_field("x", ref["k6/x"].astype(np.float32))
+    h.set_field("F_trial", ref["k6/F_trial"].astype(np.float32).reshape(-1, 9))
+    gs_num = int(g["gs_num"])
+    c6 = h.export_particle_cov_to_torch().cpu().numpy().reshape(-1, 6)
+    assert rel_l2(c6, g["cov"]) < 1e-6                                       # compute_cov_from_F, mpm_utils.py:529-553
+    for rots in (g["rot_f64"], g["rot_f32"]):                                # the caller's matrices in either precision
+        pos, cov = h.export_frame_for_rendering(gs_num, float(g["scale_origin"]), torch.tensor(g["mean"]), [torch.tensor(R) for R in rots],
+                                                z_shift_value=float(g["z_shift"]))
+        assert pos.shape == (gs_num, 3) and cov.shape == (gs_num, 6)
+        e_pos, e_cov = rel_l2(pos.cpu().numpy(), g["pos_f64"]), rel_l2(cov.cpu().numpy(), g["cov_f64"])
+        print(f"frame export vs the reference's code (f64): pos {e_pos:.2e} cov {e_cov:.2e}; the reference's own f32 run: "
+              f"pos {rel_l2(g['pos_f32'], g['pos_f64']):.2e} cov {rel_l2(g['cov_f32'], g['cov_f64']):.2e}")
+        assert e_pos < 1e-6 and e_cov < 2e-6
