@@ -6,9 +6,13 @@ rough scenes: every material id, every boundary-condition type, every particle m
 elements.  `pixie_amd.mpm_solver.MPM_Simulator_WARP` is driven through the same calls (tests/_mpm_ref_driver.py: the
 reference's method names and arguments) and compared field by field at every checkpoint.
 
-Bars (float32 product against the float64 evaluation of the reference): each field's rel-L2 <= max(1e-4, 8 x the distance
-of the reference's own code evaluated in float32 from its float64 self, which the fixture records per field).  The
-positions are held through the displacement x - x0 (the signal), not through the O(1) coordinate.
+Bars (float32 product against the float64 evaluation of the reference): each field's rel-L2 <= max(1e-5, 4 x the distance
+of the reference's own code evaluated in float32 from its float64 self, which the fixture records per field) -- ten times
+tighter than the north-star's 1e-4.  The positions are held through the displacement x - x0 (the signal), not through the
+O(1) coordinate; after one substep that displacement is ~1e-4 of the coordinate, so its relative error IS the float32
+rounding of x (5e-4, the same number for the reference's own float32 run): bar 2 x that drift.
+Measured (profiles/r4a_product_vs_reference_code.txt): v <= 1.3e-6, C <= 4.3e-6, F / F_trial <= 3.8e-7, stress <= 5.2e-6,
+yield stress <= 1.7e-7 over all ten scenes and both scatter modes; displacement at 1.00 x the reference's float32 drift.
 """
 import os
 
@@ -42,7 +46,7 @@ def test_product_equals_reference_code(hip_device, name, bits):
             want, got = ref[f"k{cp}/{f}"], snaps[cp][f].reshape(ref[f"k{cp}/{f}"].shape)
             if f == "x":
                 want, got = want - arrays["x0"], got - arrays["x0"]
-            err, bar = rel(got, want), max(1e-4, 8 * drift[f])
+            err, bar = rel(got, want), (max(1e-5, 2 * drift[f]) if f == "x" else max(1e-5, 4 * drift[f]))
             report.append(f"k{cp} {f}: {err:.2e} (reference f32 drift {drift[f]:.2e})")
             if not err < bar:
                 bad.append(report[-1])
@@ -51,7 +55,7 @@ def test_product_equals_reference_code(hip_device, name, bits):
     report.append(f"cov {e_cov:.2e}  R {e_R:.2e}")
     print(name, bits, "; ".join(report))
     assert not bad, bad
-    assert e_cov < 1e-4 and e_R < 1e-4
+    assert e_cov < 1e-5 and e_R < 1e-5
     assert np.array_equal(ad.read("material").astype(np.int64), ref["material"].astype(np.int64))
     assert abs(ad.time - float(ref["time"])) < 1e-12
     assert ad.s.out_of_bounds == 0
