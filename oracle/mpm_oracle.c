@@ -32,6 +32,15 @@
 #ifndef REAL
 #define REAL float
 #endif
+/* Only the third build (Makefile: libmpm_oracle_f32_omp.so, -fopenmp), used by bench.py's cpu_baseline leg, is
+ * multi-threaded: the pragmas below are no-ops in the two builds the tests use, whose sums keep the serial order. */
+#ifdef _OPENMP
+#define OMP_FOR _Pragma("omp parallel for schedule(static)")
+#define OMP_ATOMIC _Pragma("omp atomic")
+#else
+#define OMP_FOR
+#define OMP_ATOMIC
+#endif
 typedef REAL real;
 
 /* Literals inside the reference's kernels are float32 constants, and every scalar that reaches a kernel -- struct members
@@ -663,6 +672,7 @@ void mpm_pre_p2g(MPM *s, double dt_d) {
 /* compute_stress_from_F_trial, mpm_utils.py:467-526 */
 void mpm_compute_stress(MPM *s, double dt_d) {
     real dt = P_(dt_d);
+    OMP_FOR
     for (int p = 0; p < s->n; ++p) {
         int material = s->material[p];
         if (s->selection[p] != 0) continue;
@@ -713,12 +723,17 @@ static int stencil_inside(const MPM *s, const int *base) {
 /* p2g_apic_with_stress, mpm_utils.py:338-394 */
 void mpm_p2g(MPM *s, double dt_d) {
     real dt = P_(dt_d);
+    OMP_FOR
     for (int p = 0; p < s->n; ++p) {
         if (s->selection[p] != 0) continue;
         const real *stress = s->stress + 9 * p;
         int base[3]; real fx[3], w[3][3], dw[3][3];
         stencil(s, s->x + 3 * p, base, fx, w, dw);
-        if (!stencil_inside(s, base)) { s->oob++; continue; } /* reference: no bounds check (UB) */
+        if (!stencil_inside(s, base)) { /* reference: no bounds check (UB) */
+            OMP_ATOMIC
+            s->oob++;
+            continue;
+        }
         /* C' and -vol*stress do not depend on (i,j,k); the reference recomputes them per node
          * (:372-381) with identical operands, so hoisting is value-preserving. */
         real C[9], nvs[9];
@@ -741,9 +756,13 @@ void mpm_p2g(MPM *s, double dt_d) {
                     m_vec(C, dpos, Cd);
                     real wm = weight * s->mass[p];
                     size_t gi = GI(s, base[0] + i, base[1] + j, base[2] + k);
-                    for (int d = 0; d < 3; ++d)
-                        s->grid_v_in[3 * gi + d] += wm * (s->v[3 * p + d] + Cd[d]) + dt * ef[d];
-                    s->grid_m[gi] += wm;
+                    for (int d = 0; d < 3; ++d) {
+                        real add = wm * (s->v[3 * p + d] + Cd[d]) + dt * ef[d];
+                        OMP_ATOMIC
+                        s->grid_v_in[3 * gi + d] += add;          /* wp.atomic_add, mpm_utils.py:393 */
+                    }
+                    OMP_ATOMIC
+                    s->grid_m[gi] += wm;                           /* :394 */
                 }
     }
 }
@@ -752,6 +771,7 @@ void mpm_p2g(MPM *s, double dt_d) {
 void mpm_grid_update(MPM *s, double dt_d) {
     real dt = P_(dt_d);
     size_t G = (size_t)s->ng * s->ng * s->ng;
+    OMP_FOR
     for (size_t gi = 0; gi < G; ++gi)
         if (s->grid_m[gi] > R_(1e-15)) {
             real inv = R_(1.0) / s->grid_m[gi];
@@ -762,6 +782,7 @@ void mpm_grid_update(MPM *s, double dt_d) {
 void mpm_grid_damping(MPM *s) {
     if (!(s->grid_v_damping_scale < R_(1.0))) return;
     size_t G = (size_t)s->ng * s->ng * s->ng;
+    OMP_FOR
     for (size_t i = 0; i < 3 * G; ++i) s->grid_v_out[i] = s->grid_v_out[i] * s->grid_v_damping_scale;
 }
 
@@ -771,6 +792,7 @@ void mpm_apply_bcs(MPM *s, double dt_d) {
     int ng = s->ng;
     for (int k = 0; k < s->n_bc; ++k) {
         BC *b = &s->bcs[k];
+        OMP_FOR
         for (int ix = 0; ix < ng; ++ix)
             for (int iy = 0; iy < ng; ++iy)
                 for (int iz = 0; iz < ng; ++iz) {
@@ -826,11 +848,16 @@ void mpm_apply_bcs(MPM *s, double dt_d) {
 /* g2p, mpm_utils.py:412-463 (update_cov_with_F is always False in the reference flows) */
 void mpm_g2p(MPM *s, double dt_d) {
     real dt = P_(dt_d);
+    OMP_FOR
     for (int p = 0; p < s->n; ++p) {
         if (s->selection[p] != 0) continue;
         int base[3]; real fx[3], w[3][3], dw[3][3];
         stencil(s, s->x + 3 * p, base, fx, w, dw);
-        if (!stencil_inside(s, base)) { s->oob++; continue; }
+        if (!stencil_inside(s, base)) {
+            OMP_ATOMIC
+            s->oob++;
+            continue;
+        }
         real nv[3] = {0, 0, 0}, nC[9] = {0}, nF[9] = {0};
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
