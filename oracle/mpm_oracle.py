@@ -24,7 +24,7 @@ NAME_TO_MATERIAL_ID = {"jelly": 0, "metal": 1, "sand": 2, "snow": 5, "stationary
 
 def build(force: bool = False) -> None:
     """Compile both precisions of the C oracle with gcc (seconds)."""
-    outs = [os.path.join(_HERE, "build", f"libmpm_oracle_{p}.so") for p in ("f32", "f64", "f32_omp")]
+    outs = [os.path.join(_HERE, "build", f"libmpm_oracle_{p}.so") for p in ("f32", "f64", "f32_omp", "f64_omp")]
     src = os.path.join(_HERE, "mpm_oracle.c")
     fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(src) for o in outs)
     if force or not fresh:
@@ -91,7 +91,7 @@ class OracleMPM:
 
     def __init__(self, n_particles: int, n_grid: int = 100, grid_lim: float = 1.0, precision: str = "f32"):
         self.precision = precision
-        self.dtype = np.float64 if precision == "f64" else np.float32     # "f32", "f32_omp" (multi-core build, bench only)
+        self.dtype = np.float64 if precision.startswith("f64") else np.float32     # "*_omp": the multi-core builds (bench, driver runs)
         self._lib = lib(precision)
         self.n_particles = int(n_particles)
         self.n_grid = int(n_grid)
@@ -113,7 +113,7 @@ class OracleMPM:
         ptr = self._lib.mpm_field(self._h, name.encode(), C.byref(cnt), C.byref(is_int))
         if not ptr:
             raise KeyError(name)
-        ctype = C.c_int if is_int.value else (C.c_double if self.precision == "f64" else C.c_float)
+        ctype = C.c_int if is_int.value else (C.c_double if self.precision.startswith("f64") else C.c_float)
         arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt.value,))
         n = self.n_particles
         if name in ("x", "v"):
