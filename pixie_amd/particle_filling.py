@@ -6,8 +6,11 @@ Mirrors third_party/PhysGaussian/particle_filling/filling.py -- `fill_particles`
     +from pixie_amd.particle_filling import *
 and no Taichi.  The kernels are in csrc/particle_filling.hip; there is no CPU path.  Differences a caller can observe:
 the random offsets of new particles inside their cells come from a counter-based hash instead of ti.random() and the new
-particles are returned in a canonical order, so the whole output is reproducible for a given `seed=`; `smooth=True` (mcubes.smooth, a host-side third-party routine) raises NotImplementedError; running out of
-`max_samples` raises instead of writing past the buffer.
+particles are returned in a canonical order, so the whole output is reproducible for a given `seed=`; running out of
+`max_samples` raises instead of writing past the buffer.  `smooth=True` (filling.py:351-358 hands the density grid to the
+third-party `mcubes.smooth(..., method="constrained", max_iters=500)` on the host) runs `smooth_constrained` below on the
+device: a restatement of PyMCubes' published algorithm (the package is not installed in this image, so that one step is
+unpinned; oracle/filling_oracle.py holds the scipy restatement the device version is tested against).
 """
 from __future__ import annotations
 
@@ -18,7 +21,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-__all__ = ["fill_particles", "get_particle_volume", "init_filled_particles"]
+__all__ = ["fill_particles", "get_particle_volume", "init_filled_particles", "smooth_constrained"]
 
 
 def _dev(t: torch.Tensor) -> torch.device:
@@ -60,12 +63,93 @@ def density_grids(pos, opacity, cov, grid_n: int, grid_dx: float):
     return count, density
 
 
+def _edt_squared(inside: torch.Tensor) -> torch.Tensor:
+    """Exact squared Euclidean distance of every True voxel to the nearest False voxel (0 on False voxels): the separable
+    min-plus form, one axis at a time -- g(i) = min_j f(j) + (i - j)^2 -- as whole-array shifted minima on the device.
+    Voxels beyond the array are not background (scipy.ndimage.distance_transform_edt's convention)."""
+    big = float(3 * max(inside.shape) ** 2 + 1)
+    f = torch.where(inside, torch.full((), big, device=inside.device), torch.zeros((), device=inside.device)).float()
+    for axis in range(3):
+        n = f.shape[axis]
+        g = f.clone()
+        top = float(f.max())
+        d = 1
+        while d < n and d * d < top:
+            lo = f.narrow(axis, 0, n - d) + float(d * d)       # candidate from the voxel d steps before / after
+            g.narrow(axis, d, n - d).copy_(torch.minimum(g.narrow(axis, d, n - d), lo))
+            hi = f.narrow(axis, d, n - d) + float(d * d)
+            g.narrow(axis, 0, n - d).copy_(torch.minimum(g.narrow(axis, 0, n - d), hi))
+            d += 1
+        f = g
+    return f
+
+
+def signed_distance(density: torch.Tensor) -> torch.Tensor:
+    """PyMCubes `signed_distance_function` of the binary volume (density != 0): positive inside, the surface half a voxel
+    outside the outermost inside voxel."""
+    inside = density != 0
+    return torch.where(inside, _edt_squared(inside).double().sqrt() - 0.5, -(_edt_squared(~inside).double().sqrt() - 0.5))
+
+
+def smooth_constrained(density: torch.Tensor, max_iters: int = 500, rel_tol: float = 1e-6, band_radius: int = 4) -> torch.Tensor:
+    """mcubes.smooth(df, method="constrained", max_iters=500) on the device (see the module docstring; the algorithm is
+    stated step by step in oracle/filling_oracle.py: smooth_constrained).  Dense-grid form of the sparse system: with b the
+    band mask and, per axis, y = F u the second differences whose out-of-band neighbours are replaced by the voxel itself,
+    (Q u)_c = sum_axis [ F_cc y_c + b_{c-1} y_{c-1} + b_{c+1} y_{c+1} ],  Q_cc = sum_axis [ F_cc^2 + b_{c-1} + b_{c+1} ],
+    F_cc = -2 + (number of out-of-band neighbours along the axis).  float64 throughout, as the reference's numpy code."""
+    u0 = signed_distance(density)
+    band = u0.abs() < band_radius
+    if not bool(band.any()):
+        return u0
+    b = band.double()
+
+    def shift(t, axis, step):      # t at (c + step) along axis, 0 beyond the array
+        out = torch.zeros_like(t)
+        n = t.shape[axis]
+        if step == 1:
+            out.narrow(axis, 0, n - 1).copy_(t.narrow(axis, 1, n - 1))
+        else:
+            out.narrow(axis, 1, n - 1).copy_(t.narrow(axis, 0, n - 1))
+        return out
+    nb = [(shift(b, a, -1), shift(b, a, 1)) for a in range(3)]
+    fcc = [-2.0 + (1.0 - m) + (1.0 - p) for m, p in nb]
+    qdiag = sum(fcc[a] ** 2 + nb[a][0] + nb[a][1] for a in range(3))
+    inv_d = torch.where(band, 1.0 / qdiag, torch.zeros_like(qdiag))
+
+    def apply_q(x):                # x is zero outside the band; returns (Q x, sum |F x|^2)
+        qx = torch.zeros_like(x)
+        energy = x.new_zeros(())
+        for a in range(3):
+            y = (fcc[a] * x + shift(x, a, -1) + shift(x, a, 1)) * b
+            energy = energy + (y * y).sum()
+            qx = qx + fcc[a] * y + shift(y, a, -1) + shift(y, a, 1)
+        return qx * b, energy
+    x = u0 * b
+    inf = torch.full_like(x, float("inf"))
+    upper = torch.where(x < 0, x, inf)
+    lower = torch.where(x > 0, x, -inf)
+    upper = torch.where(upper.abs() < 1, torch.zeros_like(x), upper)
+    lower = torch.where(lower.abs() < 1, torch.zeros_like(x), lower)
+    upper = torch.where(band, upper, torch.zeros_like(x))
+    lower = torch.where(band, lower, torch.zeros_like(x))
+    check_each, weight = 10, 0.5
+    cum_rel_tol = 1 - (1 - rel_tol) ** check_each
+    energy_now = float(apply_q(x)[1]) / 2
+    for i in range(max_iters):
+        qx, _ = apply_q(x)
+        x = weight * (-(qx - qdiag * x) * inv_d) + (1 - weight) * x
+        x = torch.minimum(torch.maximum(x, lower), upper)
+        if (i + 1) % check_each == 0:
+            energy_before, energy_now = energy_now, float(apply_q(x)[1]) / 2
+            if (energy_before - energy_now) / energy_before < cum_rel_tol:
+                break
+    return torch.where(band, x, u0)
+
+
 def fill_particles(pos, opacity, cov, grid_n: int, max_samples: int, grid_dx: float, density_thres=2.0, search_thres=1.0,
                    max_particles_per_cell=1, search_exclude_dir=5, ray_cast_dir=4, boundary: list = None, smooth: bool = False,
                    seed: int = 0, return_grids: bool = False):
     """filling.py:291-380.  Returns cat([pos, new particles]); with return_grids also (count, density, n_dense, n_total)."""
-    if smooth:
-        raise NotImplementedError("smooth=True runs mcubes.smooth on the host in the reference; not reproduced")
     dev = _dev(pos)
     lib = _lib.load()
     pos_clone = pos.detach().to(dev, torch.float32).clone()
@@ -91,6 +175,9 @@ def fill_particles(pos, opacity, cov, grid_n: int, max_samples: int, grid_dx: fl
                                      _p(particles), int(max_samples), _p(counter), int(seed) & 0xFFFFFFFF, st), "pixie_fill_dense_cells")
     n_dense = int(counter.item())
     print("after dense grids: ", n_dense)
+    if smooth:    # filling.py:351-358: the density grid becomes the constrained-smoothed signed distance of its support
+        density = smooth_constrained(density, max_iters=500).to(torch.float32).contiguous()
+        print("smooth finished")
     check(lib.pixie_fill_internal_cells(_p(count), _p(density), int(grid_n), float(grid_dx), int(max_particles_per_cell), int(search_exclude_dir),
                                         int(ray_cast_dir), float(search_thres), _p(particles), int(max_samples), _p(counter),
                                         int(seed) & 0xFFFFFFFF, st), "pixie_fill_internal_cells")

@@ -114,3 +114,35 @@ def test_particle_volume_and_init_filled(hip_device):
     assert s2.shape == (3700, 16, 3) and o2.shape == (3700, 1) and c2.shape == (3700, 6)
     assert np.array_equal(s2[3000:].cpu().numpy(), shs[idx]) and np.array_equal(c2[3000:].cpu().numpy(), cov[idx])
     assert np.array_equal(o2[3000:, 0].cpu().numpy(), opa[idx, 0]) and np.array_equal(s2[:3000].cpu().numpy(), shs)
+
+
+def test_fill_particles_with_smoothing(hip_device):
+    """fill_particles(smooth=True) -- filling.py:351-358 replaces the density grid by mcubes.smooth(df, "constrained", 500) before
+    the internal filling (PhysGaussian/config/objaverse/custom_sand_config.json:39, custom_rocks_config.json:40 set it).  The
+    product's device implementation against the oracle's scipy restatement of the same published algorithm, then the
+    filled cells against the oracle's internal_cells on the smoothed grid."""
+    from pixie_amd.particle_filling import fill_particles, smooth_constrained
+    n, dx = 40, 1.0 / 40
+    pos, op, cov = shell_scene(n=9000, seed=4)
+    pos32, op32, cov32 = (torch.from_numpy(a.astype(np.float32)).to(hip_device) for a in (pos, op, cov))
+    dens_thr, search_thr, ppc = 2.0, 3.0, 1                      # search_threshold 3 is decode_param.py's default
+    out, count_d, dens_d, n_dense, n_total = fill_particles(pos32, op32[:, None], cov32, n, 300_000, dx, density_thres=dens_thr, search_thres=search_thr,
+                                                            max_particles_per_cell=ppc, search_exclude_dir=5, ray_cast_dir=4, smooth=True, seed=5, return_grids=True)
+    dens_h = dens_d.cpu().numpy().astype(np.float64)            # the grid as densify_grids left it (float32 atomics)
+    sm_dev = smooth_constrained(dens_d).cpu().numpy()
+    sm_ref = fo.smooth_constrained(dens_h, max_iters=500)
+    assert np.abs(sm_dev - sm_ref).max() < 1e-9
+    count0 = fo.densify(pos32.cpu().numpy(), op, cov32.cpu().numpy(), n, dx)[0]
+    dense, per = fo.dense_cells(count0, dens_h, dens_thr, ppc)
+    count1 = np.where(dense, ppc, count0)
+    inside = fo.internal_cells(count1, sm_ref.astype(np.float32), search_thr, 5, 4)
+    final = np.where(inside, ppc, count1)
+    near = np.abs(dens_h - dens_thr) < 1e-4 * dens_thr
+    if near.sum() == 0:
+        assert np.array_equal(count_d.cpu().numpy(), final)
+        assert n_total == int(per.sum() + ppc * inside.sum())
+    assert inside.sum() > 200                                    # the smoothed shell still encloses an interior that gets filled
+    # and it is a different set from the unsmoothed run's (the threshold now reads a distance, not a density)
+    plain = fo.internal_cells(count1, dens_h, search_thr, 5, 4)
+    assert (plain != inside).sum() > 0
+    assert out.shape[0] == len(pos32) + n_total

@@ -132,3 +132,68 @@ def test_torus_interior_by_ray_parity():
     deep = rho < r - 3.5 * dx                               # cells well inside, clear of the splatted shell
     assert deep.sum() > 800 and filled[deep].mean() > 0.999
     assert not filled[n // 2, n // 2, n // 2]               # the centre of the hole
+
+
+# ----------------------------------------------------------------------------- mcubes.smooth(df, method="constrained")
+def _blob(n=36, seed=0):
+    rng = np.random.default_rng(seed)
+    g = np.arange(n) - (n - 1) / 2
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    inside = ((X / 12) ** 2 + (Y / 8) ** 2 + (Z / 10) ** 2 < 1) | ((X - 5) ** 2 + (Y - 4) ** 2 + (Z + 4) ** 2 < 30)
+    inside &= ~((X + 3) ** 2 + Y ** 2 + Z ** 2 < 8)                      # with a cavity
+    return inside * rng.uniform(0.5, 5.0, inside.shape)
+
+
+def test_signed_distance_against_brute_force():
+    df = _blob(18, 1)
+    u0 = fo.signed_distance(df)
+    inside = df != 0
+    pts_in, pts_out = np.argwhere(inside), np.argwhere(~inside)
+    for c in np.argwhere(np.ones_like(inside))[::7]:
+        other = pts_out if inside[tuple(c)] else pts_in
+        d = np.sqrt(((other - c) ** 2).sum(1).min()) - 0.5
+        assert abs(u0[tuple(c)] - (d if inside[tuple(c)] else -d)) < 1e-12
+
+
+def test_constrained_smoothing_properties():
+    """PyMCubes is not installed (the step is unpinned): what the restatement must satisfy by construction of the method."""
+    df = _blob()
+    u0 = fo.signed_distance(df)
+    s = fo.smooth_constrained(df, max_iters=500)
+    band = np.abs(u0) < 4
+    assert np.array_equal(s[~band], u0[~band])                            # only the band moves
+    assert np.abs(s - u0).max() > 0.3                                     # and it does move
+    inside = df != 0
+    assert (s[inside] >= 0).all() and (s[~inside] <= 0).all()             # the surface never crosses a voxel centre
+    far = np.abs(u0) >= 1
+    assert (s[inside & far] >= u0[inside & far] - 1e-12).all()            # inside values only grow, outside values only fall
+    assert (s[~inside & far] <= u0[~inside & far] + 1e-12).all()
+    # the functional 1/2 |F u|^2 (second differences inside the band, replicated ends) went down
+    def energy(u):
+        e = 0.0
+        for axis in range(3):
+            um, up = np.roll(u, 1, axis), np.roll(u, -1, axis)
+            bm, bp = np.roll(band, 1, axis), np.roll(band, -1, axis)
+            y = np.where(bm, um, u) + np.where(bp, up, u) - 2 * u
+            e += float((y[band] ** 2).sum())
+        return e / 2
+    assert energy(s) < 0.6 * energy(u0)
+    # more sweeps never raise it; the result depends on the support of the density only
+    assert energy(fo.smooth_constrained(df, max_iters=20)) >= energy(s) - 1e-9
+    assert np.array_equal(fo.smooth_constrained((df != 0).astype(float)), s)
+    # symmetric input -> symmetric output
+    cube = np.zeros((24, 24, 24)); cube[6:18, 6:18, 6:18] = 1.0
+    sc = fo.smooth_constrained(cube)
+    assert np.allclose(sc, sc[::-1]) and np.allclose(sc, sc.transpose(1, 0, 2)) and np.allclose(sc, sc.transpose(2, 1, 0)[:, :, ::-1])
+    # the corners of the cube are rounded: the field at a corner voxel is pulled onto the surface (its bound, 0), a face centre is not
+    assert sc[6, 6, 6] < 0.25 and sc[6, 12, 12] >= 0.5
+
+
+def test_device_implementation_of_the_smoothing_equals_the_oracle():
+    """pixie_amd.particle_filling.smooth_constrained is whole-array torch arithmetic (the product runs it on the GPU inside
+    fill_particles(smooth=True)); on CPU tensors it must reproduce the scipy restatement."""
+    import torch
+    from pixie_amd.particle_filling import signed_distance, smooth_constrained
+    df = _blob(30, 2)
+    assert np.abs(signed_distance(torch.from_numpy(df)).numpy() - fo.signed_distance(df)).max() < 1e-12
+    assert np.abs(smooth_constrained(torch.from_numpy(df)).numpy() - fo.smooth_constrained(df)).max() < 1e-9
