@@ -48,24 +48,47 @@ def shard_scenes(n_scenes: int, rank: int, world: int) -> List[int]:
     return idx[rank:total:world]
 
 
-def pack_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(n, 3, D, H, W) fp32, (n, D, H, W) int -> wire tensors (fp32, uint8), contiguous."""
-    return cont_pred.contiguous().to(torch.float32), seg_pred.contiguous().to(torch.uint8)
+def wire_bytes(n_local: int, voxels: int) -> int:
+    """Bytes one rank contributes: n_local scenes x (3 fp32 + 1 uint8) per voxel = 13 B/voxel, padded to 16 B so that every
+    rank's float32 block starts aligned inside the gathered buffer."""
+    return (13 * n_local * voxels + 15) // 16 * 16
+
+
+def pack_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor) -> torch.Tensor:
+    """(n, 3, D, H, W) fp32 + (n, D, H, W) integer class ids -> ONE uint8 wire buffer: [n * 3 * V floats | n * V bytes | pad]."""
+    n, vox = cont_pred.shape[0], seg_pred[0].numel() if seg_pred.shape[0] else 0
+    buf = torch.empty(wire_bytes(n, vox), dtype=torch.uint8, device=cont_pred.device)
+    nf = 12 * n * vox
+    buf[:nf].view(torch.float32).copy_(cont_pred.reshape(-1))          # dtype conversion (if any) rides in the copy kernel
+    buf[nf:nf + n * vox].copy_(seg_pred.reshape(-1))
+    if buf.numel() > nf + n * vox:
+        buf[nf + n * vox:].zero_()
+    return buf
+
+
+def unpack_fields(buf: torch.Tensor, world: int, n_local: int, spatial: Tuple[int, ...]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The gathered wire buffer (world x wire_bytes) -> (world * n_local, 3, D, H, W) fp32, (world * n_local, D, H, W) uint8, rank-major."""
+    vox = 1
+    for d in spatial:
+        vox *= int(d)
+    nf = 12 * n_local * vox
+    rows = buf.view(world, -1)
+    cont = rows[:, :nf].view(torch.float32).reshape((world * n_local, 3) + tuple(spatial))
+    seg = rows[:, nf:nf + n_local * vox].reshape((world * n_local,) + tuple(spatial))
+    return cont, seg
 
 
 def all_gather_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-gather the local scenes' fields; returns tensors ordered rank-major:
-    (world * n_local, 3, D, H, W) fp32 and (world * n_local, D, H, W) uint8.
-    With world == 1 (or no process group) it returns the inputs unchanged."""
-    cont, seg = pack_fields(cont_pred, seg_pred)
+    """All-gather the local scenes' fields with ONE collective on the packed 13 B/voxel buffer (two
+    collectives -- fp32, then uint8 -- until round 3).  Returns tensors ordered rank-major: (world * n_local, 3, D, H, W) fp32
+    and (world * n_local, D, H, W) uint8.  With world == 1 (or no process group) nothing is packed or copied."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return cont, seg
+        return cont_pred.contiguous().to(torch.float32), seg_pred.contiguous().to(torch.uint8)
     world = dist.get_world_size()
-    cont_out = torch.empty((world * cont.shape[0],) + tuple(cont.shape[1:]), dtype=cont.dtype, device=cont.device)
-    seg_out = torch.empty((world * seg.shape[0],) + tuple(seg.shape[1:]), dtype=seg.dtype, device=seg.device)
-    dist.all_gather_into_tensor(cont_out, cont)  # concatenation along dim 0, rank-major
-    dist.all_gather_into_tensor(seg_out, seg)
-    return cont_out, seg_out
+    mine = pack_fields(cont_pred, seg_pred)
+    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)        # concatenation along dim 0, rank-major
+    return unpack_fields(out, world, cont_pred.shape[0], tuple(seg_pred.shape[1:]))
 
 
 def unshard_order(n_scenes: int, world: int) -> List[int]:

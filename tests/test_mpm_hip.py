@@ -556,8 +556,13 @@ def test_boundary_conditions_and_modifiers(hip_device):
     assert rel_l2(get(h, "x"), o.field("x")) < 1e-5
     drift = rel_l2(o32.field("v"), o.field("v"))
     err = rel_l2(get(h, "v"), o.field("v"))
-    print(f"bc test v @30: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}")
-    assert err < max(1e-3, 2 * drift)
+    direct = rel_l2(get(h, "v"), o32.field("v"))
+    print(f"bc test v @30: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  hip-vs-oracle-f32 {direct:.3e}")
+    # the common bar of this file (this test alone allowed 1e-3).  The float32 and float64 oracles differ by
+    # ~1e-2 here for a systematic reason -- the velocity pins and the impulse window act on float32 time / float32 state --
+    # and the HIP solver follows the float32 arithmetic, so it is ALSO held to the float32 oracle directly.
+    assert err < max(1e-4, 4 * drift)
+    assert direct < 1e-4
     assert rel_l2(get(h, "F_trial").reshape(-1, 3, 3), o.field("F_trial")) < 1e-4
     # 20 more: through the cuboid's end_time and its 15-substep "reset" window, which zeroes the whole grid
     # (mpm_solver_warp.py:895-897); afterwards v restarts from roundoff-sized forces, so it is only required to be
@@ -567,8 +572,8 @@ def test_boundary_conditions_and_modifiers(hip_device):
     assert rel_l2(get(h, "F_trial").reshape(-1, 3, 3), o.field("F_trial")) < 1e-4
     drift = rel_l2(o32.field("v"), o.field("v"))
     err = rel_l2(get(h, "v"), o.field("v"))
-    print(f"bc test v @50: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}")
-    assert err < max(1e-3, 2 * drift)
+    print(f"bc test v @50: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  hip-vs-oracle-f32 {rel_l2(get(h, 'v'), o32.field('v')):.3e}")
+    assert err < max(1e-4, 4 * drift)
 
 
 def test_regrid_after_load_keeps_everything_but_the_grid(hip_device):

@@ -725,8 +725,9 @@ def test_network_256_cube_128_features(hip_device):
     f16x3 kernels of the same block on the device; (a) vs the recorded fp32-path output and (a) vs (b) are both held to
     1e-5.  Blocks: stem (projector 128 -> 128 -> 128 (3^3) -> 32 + input conv, all at 256^3), a full-resolution residual
     block, the first down-sampling conv, a 128^3 residual block, the decoder block that up-samples back to 256^3, the last
-    decoder block (concatenated 128-channel input, folded 1x1x1 skip) and the head: every operator variant that runs at
-    256^3, where a 64-channel tensor is 4.3 GB (beyond 32-bit byte offsets).  Then both heads end to end, f16x3 against
+    decoder block (concatenated 128-channel input, folded 1x1x1 skip), the middle block's AttentionBlock at T = 32 768 tokens
+    (diffusion_network.py:192-242; the oracle materialises the 4 GiB logit matrix, the kernel streams the softmax) and the
+    head: every operator variant that runs at 256^3, where a 64-channel tensor is 4.3 GB (beyond 32-bit byte offsets).  Then both heads end to end, f16x3 against
     exact fp32, with the timing of the f16x3 scene."""
     import time
     import psutil
@@ -751,6 +752,9 @@ def test_network_256_cube_128_features(hip_device):
     feeds = {"unet.input_blocks.1": ["unet.input_blocks.0"], "unet.input_blocks.4": ["unet.input_blocks.3"],
              "unet.input_blocks.5": ["unet.input_blocks.4"], "unet.output_blocks.11": ["unet.output_blocks.10", "unet.input_blocks.4"],
              "unet.output_blocks.15": ["unet.output_blocks.14", "unet.input_blocks.0"]}
+    # the middle block's attention at T = (256/8)^3 = 32 768 tokens (a 4 GiB logit matrix in the reference; streamed here)
+    blocks["unet.middle_block.1"] = [middle[1]]
+    feeds["unet.middle_block.1"] = ["unet.middle_block.0"]
     want = {k: None for k in set(blocks) | {v for vs in feeds.values() for v in vs} | {"unet.input_blocks.0"}}
     seg.conv_precision = "f32"
     taps = dict(want)
