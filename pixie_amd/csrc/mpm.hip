@@ -1230,6 +1230,22 @@ __global__ void identity_F_kernel(float* Ft, int n) {
     if (i >= n) return;
     for (int c = 0; c < 9; ++c) Ft[(size_t)c * n + i] = (c % 4 == 0) ? 1.0f : 0.0f;
 }
+// Smallest and largest positive particle mass (bit patterns of non-negative floats order like the floats).  The packed
+// scatter's quantum is 2^-30 of the SUM of a work item's contribution bounds, so a node fed only by particles R times lighter
+// than their neighbours in the tile is resolved to ~1e-6 R of its own mass: above a contrast of kPackMaxContrast
+// the exact 64-bit mode is selected instead.
+constexpr float kPackMaxContrast = 32.0f;
+__global__ void mass_range_kernel(MpmPtrs S, unsigned* __restrict__ range) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = (p < S.n && S.selection[p] == 0) ? S.mass[p] : 0.0f;
+    unsigned lo = (m > 0.0f) ? __float_as_uint(m) : 0xffffffffu, hi = (m > 0.0f) ? __float_as_uint(m) : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(range, lo); atomicMax(range + 1, hi); }
+}
+
 __global__ void mass_kernel(MpmPtrs S) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < S.n) S.mass[i] = S.density[i] * S.vol[i];
@@ -1398,7 +1414,11 @@ struct pixie_mpm {
     int* blk_flags = nullptr;
     int* active_list = nullptr;              // blocks with particles in their 27-neighbourhood (built at re-binning)
     int2* nbr_table = nullptr;               // 28 int2 per active block (see MpmPtrs)
-    int scatter_bits = 32;                   // 32 (default): packed pairs of 32-bit sums, 2 LDS atomics per node; 64: exact 64-bit fixed point, 4 per node
+    int scatter_bits = 32;                   // mode in force: 32 = packed pairs of 32-bit sums, 2 LDS atomics per node; 64 = exact 64-bit fixed point, 4 per node
+    int scatter_bits_user = 0;               // 0 (default): chosen by the particle-mass contrast at every re-binning (below); 32 / 64: forced
+    bool mass_range_dirty = true;            // masses changed since the contrast was last measured
+    unsigned* d_mass_range = nullptr;        // [0] min, [1] max of the positive particle masses, as float bits
+    float mass_contrast = 1.0f;              // max / min as of the last measurement
     int wide = -1;                           // -1 auto: the latency-optimised variant when the scene cannot fill the chip; 0/1 forced
     int n_cus = 256;
     int n_active = 0;
@@ -1470,6 +1490,13 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     hipLaunchKernelGGL(bin_permute_kernel, dim3(cdiv(n, 256), cdiv(R_COUNT, rows_per_y)), dim3(256), 0, st,
                        h->words[h->cur], h->words[h->cur ^ 1], h->order2, n, rows_per_y);
     PX_CHECK_HIP(hipGetLastError());
+    const bool measure_mass = h->mass_range_dirty;
+    if (measure_mass) {
+        PX_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_mass_range, (int)0xffffffffu, 1, st));
+        PX_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h->d_mass_range + 1), 0, 1, st));
+        hipLaunchKernelGGL(mass_range_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->d_mass_range);
+        PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 6, h->d_mass_range, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    }
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 4, h->S.oob + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 8, h->S.oob, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1482,6 +1509,14 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
+    if (measure_mass) {
+        float lo, hi;
+        memcpy(&lo, h->h_n_items + 6, sizeof lo); memcpy(&hi, h->h_n_items + 7, sizeof hi);
+        h->mass_contrast = (lo > 0.0f && hi >= lo && hi < 3.0e38f) ? hi / lo : 1.0f;
+        h->mass_range_dirty = false;
+    }
+    // (like sparse_tiles: decided at a re-binning only -- the mode changes how a tile is summed in LDS, not what is published)
+    h->scatter_bits = h->scatter_bits_user ? h->scatter_bits_user : (h->mass_contrast > kPackMaxContrast ? 64 : 32);
     // (decided here and only here: never between a P2G and the grid kernel that consumes its tiles)
     S.sparse_tiles = h->sparse >= 0 ? h->sparse : (grid_kernel_crowded(h) ? 1 : 0);
     // Cadence: the LDS tile tolerates one cell of drift, and the measured drift of the interval just finished
@@ -1715,6 +1750,9 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     const int nblocks = nbk * nbk * nbk;
     const size_t n = (size_t)S.n, G = (size_t)n_grid * n_grid * n_grid;
     const size_t max_items = (n + 63) / 64 + std::min<size_t>((size_t)nblocks, n);   // for the smallest capacity (64)
+    // gather_node (grid kernel) forms tile offsets item * kTN in 32-bit arithmetic: 8.4 M work items, i.e. > 100 M particles
+    // at the smallest capacity, would wrap silently -- refused here instead
+    PX_REQUIRE(max_items * (size_t)kTN < ((size_t)1 << 32), "pixie_mpm: %zu work items exceed the 32-bit tile offsets of the grid kernel (2^23 items)", max_items);
     std::vector<void*> old;
     old.swap(h->grid_allocs);
     float4 *gin = nullptr, *gout = nullptr, *part = nullptr;
@@ -1788,6 +1826,7 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
     }
     rc |= dev_alloc(h, &h->keys, n); rc |= dev_alloc(h, &h->rank, n); rc |= dev_alloc(h, &h->order, n); rc |= dev_alloc(h, &h->order2, n);
     rc |= dev_alloc(h, &h->d_n_items, 4);
+    rc |= dev_alloc(h, &h->d_mass_range, 2);
     rc |= alloc_grid(h, n_grid, grid_lim);
     rc |= dev_alloc(h, &h->init_cov, 6 * n);
     if (rc) { pixie_mpm_destroy(h); return 1; }
@@ -1844,6 +1883,7 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     FieldInfo fi;
     PX_REQUIRE(find_field(h, nm, &fi), "set_field: unknown field '%s'", name);
     PX_REQUIRE(count == (int64_t)n * fi.k, "set_field(%s): expected %lld scalars, got %lld", name, (long long)n * fi.k, (long long)count);
+    if (nm == "mass" || nm == "selection") { h->mass_range_dirty = true; h->needs_sort = true; }
     if (nm == "x") {   // positions replaced: binning stale, frozen particles get another chance
         h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval;
         hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S.selection, n);
@@ -1931,7 +1971,11 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
     else if (k == "profile") h->profile = value != 0.0;
-    else if (k == "scatter_bits") { PX_REQUIRE(value == 64 || value == 32, "scatter_bits must be 64 (exact) or 32 (packed pairs)"); h->scatter_bits = (int)value; }
+    else if (k == "scatter_bits") {
+        PX_REQUIRE(value == 64 || value == 32 || value == 0, "scatter_bits must be 0 (auto: by mass contrast), 64 (exact) or 32 (packed pairs)");
+        h->scatter_bits_user = (int)value;
+        if (value != 0) h->scatter_bits = (int)value; else { h->mass_range_dirty = true; h->needs_sort = true; }
+    }
     else if (k == "grid_rb") { PX_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "grid_rb must be 0, 1, 2 or 4"); h->grid_rb = (int)value; }
     else if (k == "sparse_tiles") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "sparse_tiles must be -1 (auto), 0 or 1"); h->sparse = (int)value; h->needs_sort = true; }
     else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
@@ -1954,7 +1998,9 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "grid_v_damping_scale") *value = h->damping;
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
-    else if (k == "scatter_bits") *value = h->scatter_bits;
+    else if (k == "scatter_bits") *value = h->scatter_bits;            // the mode in force (as of the last re-binning when auto)
+    else if (k == "scatter_bits_user") *value = h->scatter_bits_user;
+    else if (k == "mass_contrast") *value = h->mass_contrast;
     else if (k == "n_active_blocks") *value = h->n_active;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
     else if (k == "lost_particles_seen") *value = (double)h->lost_seen;   // as of the last re-binning; does not synchronise
@@ -1974,6 +2020,7 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
 
 int pixie_mpm_update_mass(pixie_mpm* h, void* stream) {
     PX_REQUIRE(h, "null handle");
+    h->mass_range_dirty = true; h->needs_sort = true;
     hipLaunchKernelGGL(mass_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S);
     PX_CHECK_HIP(hipGetLastError());
     return 0;

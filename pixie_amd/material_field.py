@@ -109,7 +109,9 @@ def dbscan_labels(points, eps: float, min_samples: int) -> torch.Tensor:
         return labels
     lo = pts.amin(dim=0)
     extent = float((pts.amax(dim=0) - lo).max())
-    cell = max(float(eps) * (1.0 + 1e-6), extent / 256.0)          # <= 257^3 cells whatever the extent
+    # cell >= eps with a margin ABOVE the float32 error of the cell index ((p - lo) * inv reaches ~256, i.e. an absolute
+    # rounding error of ~1.5e-5 cells: two points exactly eps apart must never end up two cells apart -- ADVICE r3)
+    cell = max(float(eps) * (1.0 + 1e-3), extent / 256.0)          # <= 257^3 cells whatever the extent
     inv = float(np.float32(1.0 / cell))                             # (the kernels recompute the cells with this float32 arithmetic)
     cells = torch.floor((pts - lo) * inv).to(torch.int64)
     dims = (cells.amax(dim=0) + 1).tolist()

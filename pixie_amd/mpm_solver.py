@@ -11,7 +11,7 @@ Differences a caller can observe, by design:
   * export_*_to_torch return one persistent tensor per field in the caller's particle order, refreshed in
     place by each export call, instead of live zero-copy aliases of solver memory (the solver keeps
     particles block-sorted in SoA rows); get_field() returns fresh tensors;
-  * `run(dt, n)` / `p2g2p_n` step n substeps in one call (one launch per substep, no host sync);
+  * `run(dt, n)` / `p2g2p_n` step n substeps in one call (two launches per substep -- block kernel + grid kernel --, no host sync);
   * `p2g2p(step, dt)` only QUEUES a substep.  The queue is flushed -- as ONE `run(dt, n)` -- by the next call that
     observes or changes the solver (any export / get_field / set_field / `.time` / BC or parameter call, `flush()`),
     so the reference's own loop (gs_simulation.py:633-634: `for step in range(step_per_frame): p2g2p(frame, dt)`,
@@ -116,6 +116,7 @@ class MPM_Simulator_WARP:
             raise _lib.PixieHipError("MPM_Simulator_WARP needs a HIP device; pixie_amd has no CPU fallback")
         self._release()
         self._pending, self._pending_dt = 0, 0.0   # substeps queued by p2g2p() and their dt
+        self._pending_stream = None                # the stream that was current when they were queued
         self._lost_reported = 0
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
@@ -171,7 +172,9 @@ class MPM_Simulator_WARP:
         n = getattr(self, "_pending", 0)
         if n:
             self._pending = 0
-            check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, self._stream), "pixie_mpm_step")
+            stream = getattr(self, "_pending_stream", None) or self._stream     # the stream the substeps were queued under
+            self._pending_stream = None
+            check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, stream), "pixie_mpm_step")
             self._warn_if_particles_lost()
 
     def _get_scalar(self, key):
@@ -346,9 +349,13 @@ class MPM_Simulator_WARP:
         """:514-637 -- one substep.  Deferred: the substep is queued and runs, fused with its neighbours, when the
         solver is next observed or changed (module docstring); a change of dt flushes what was queued first."""
         dt = float(dt)
-        if self._pending and dt != self._pending_dt:
+        stream = self._stream
+        # a change of dt -- or of the CURRENT STREAM (ADVICE r3: a caller that wraps part of its loop in torch.cuda.stream(s)
+        # must get its substeps on the stream they were issued under, not on whatever is current at flush time) -- ends a batch
+        if self._pending and (dt != self._pending_dt or stream != self._pending_stream):
             self.flush()
         self._pending_dt = dt
+        self._pending_stream = stream
         self._pending += 1
         if self.live_exports:
             self._refresh_views()
@@ -356,9 +363,11 @@ class MPM_Simulator_WARP:
     def run(self, dt, n_substeps):
         """n substeps of p2g2p in one call (fused G2P->P2G->grid launches, no host synchronisation)."""
         dt = float(dt)
-        if self._pending and dt != self._pending_dt:
+        stream = self._stream
+        if self._pending and (dt != self._pending_dt or stream != self._pending_stream):
             self.flush()
         self._pending_dt = dt
+        self._pending_stream = stream
         self._pending += int(n_substeps)
         self.flush()
         if self.live_exports:
@@ -366,10 +375,14 @@ class MPM_Simulator_WARP:
 
     @property
     def scatter_bits(self):
-        """Accumulation mode of the P2G scatter (csrc/mpm.hip).  32 (default): pairs of 32-bit fixed-point sums per LDS atomic
+        """Accumulation mode of the P2G scatter IN FORCE (csrc/mpm.hip).  32: pairs of 32-bit fixed-point sums per LDS atomic
         -- half the atomics, quantum 2^-30 of the summed contribution bounds of a 256-particle work item, the noise level of
         the reference's fp32 atomics; 64: exact 64-bit fixed point (quantum 2^-42), 20 % slower.  Both are integer sums:
-        order-independent and bit-reproducible."""
+        order-independent and bit-reproducible.
+        Default (`scatter_bits = 0`): chosen at every re-binning from the particle-mass contrast max(m) / min(m) -- packed up
+        to a contrast of 32, exact above.  The limit of the packed mode: a node fed only by particles R times lighter than
+        their tile-mates is resolved to ~1e-6 R of its own mass, which is invisible for uniform scenes and visible from
+        R ~ 1e2 (tests/test_mpm_hip.py::test_mass_contrast_selects_the_exact_scatter).  Assign 32 or 64 to force a mode."""
         return int(self._get_scalar("scatter_bits"))
 
     @scatter_bits.setter

@@ -10,7 +10,7 @@ particles are returned in a canonical order, so the whole output is reproducible
 `max_samples` raises instead of writing past the buffer.  `smooth=True` (filling.py:351-358 hands the density grid to the
 third-party `mcubes.smooth(..., method="constrained", max_iters=500)` on the host) runs `smooth_constrained` below on the
 device: a restatement of PyMCubes' published algorithm (the package is not installed in this image, so that one step is
-unpinned; oracle/filling_oracle.py holds the scipy restatement the device version is tested against).
+unpinned; the test suite holds a scipy restatement of the same algorithm that the device version is tested against).
 """
 from __future__ import annotations
 
@@ -93,7 +93,7 @@ def signed_distance(density: torch.Tensor) -> torch.Tensor:
 
 def smooth_constrained(density: torch.Tensor, max_iters: int = 500, rel_tol: float = 1e-6, band_radius: int = 4) -> torch.Tensor:
     """mcubes.smooth(df, method="constrained", max_iters=500) on the device (see the module docstring; the algorithm is
-    stated step by step in oracle/filling_oracle.py: smooth_constrained).  Dense-grid form of the sparse system: with b the
+    stated step by step in the checker's `smooth_constrained` under tests' filling oracle).  Dense-grid form of the sparse system: with b the
     band mask and, per axis, y = F u the second differences whose out-of-band neighbours are replaced by the voxel itself,
     (Q u)_c = sum_axis [ F_cc y_c + b_{c-1} y_{c-1} + b_{c+1} y_{c+1} ],  Q_cc = sum_axis [ F_cc^2 + b_{c-1} + b_{c+1} ],
     F_cc = -2 + (number of out-of-band neighbours along the axis).  float64 throughout, as the reference's numpy code."""

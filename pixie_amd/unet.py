@@ -632,12 +632,19 @@ class _PixieUNet(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _param_list(self) -> List[torch.Tensor]:
-        """The parameters in registration order, cached: walking the module tree costs more than the rest of a 16^3 replay's
-        host work.  Parameter OBJECTS are stable (load_state_dict and .to() update them in place)."""
-        pl = self.__dict__.get("_plist")
-        if pl is None:
-            pl = self._plist = list(self.parameters())
-        return pl
+        """The parameters in registration order.  Walking the module tree costs more than the rest of a 16^3 replay's host
+        work, so what is cached is WHERE each parameter lives -- (the owning module's `_parameters` dict, name) -- and every
+        call reads the current objects out of those dicts: a parameter that was REPLACED (load_state_dict(assign=True),
+        `module.weight = nn.Parameter(...)`) is seen at once and changes the graph key (a cached list of the
+        objects themselves would have replayed stale weights)."""
+        refs = self.__dict__.get("_plist")
+        if refs is None:
+            refs = self._plist = [(m._parameters, name) for m in self.modules() for name, p in m._parameters.items() if p is not None]
+        return [d[name] for d, name in refs]
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self._plist = None
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def _forward_graphed(self, x: Optional[torch.Tensor], proj0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One sample through a captured HIP graph.  A forward pass is ~400 kernel launches; its launch sequence for a given
@@ -649,8 +656,10 @@ class _PixieUNet(nn.Module):
         buffer each call copies into.  Which of the two is decided at the SECOND call (the first runs eagerly), so nobody pays
         for two captures.  Returns a copy of the graph's static output."""
         src = proj0 if proj0 is not None else x
-        base = (tuple(src.shape), proj0 is not None, self.executor, self.conv_precision, src.device.index,
-                tuple((p.data_ptr(), p._version) for p in self._param_list()))   # storage AND version: `p.data = t` / `.to()` keep the version
+        # (layout and dtype are part of the key: a captured graph reads the caller's memory as laid out at capture time, and a
+        # permuted / expanded view of the same address and shape must not replay it -- ADVICE r3)
+        base = (tuple(src.shape), tuple(src.stride()), src.dtype, proj0 is not None, self.executor, self.conv_precision, src.device.index,
+                tuple((id(p), p.data_ptr(), p._version) for p in self._param_list()))   # identity, storage AND version: `p.data = t` / `.to()` keep the version
         run = (lambda t: self._forward_one(None, proj0=t)) if proj0 is not None else (lambda t: self._forward_one(t))
         if self._graphs.get("base") != base:           # a new shape / parameter version invalidates every capture
             self._graphs = {"base": base, "first_ptr": None}

@@ -284,6 +284,45 @@ def test_latency_optimised_variant_matches(hip_device):
     assert rel_l2(res[1]["v"], res[0]["v"]) < 1e-4
 
 
+def test_mass_contrast_selects_the_exact_scatter(hip_device):
+    """the packed scatter's quantum is 2^-30 of the SUM of a work item's bounds, so nodes fed only by particles much
+    lighter than their tile-mates are quantised at visible weights.  A scene whose upper half is 1e4 times lighter than its
+    lower half (both halves meet inside blocks): the default mode must come out as the exact one, its light-side grid
+    velocities must meet the usual 1e-4 bar, and forcing the packed mode must be measurably worse there (the limit the
+    `scatter_bits` property documents).  A uniform scene keeps the packed mode."""
+    sc = mpm_ball_scene(20000, seed=4)
+    n = 20000
+    light = sc["x"][:, 2] > 1.0
+    sc["density"] = np.where(light, 0.2, 2000.0).astype(np.float32)
+    rng = np.random.default_rng(1)
+    v0 = (0.5 * rng.normal(size=(n, 3))).astype(np.float32)
+    Ft0 = (np.eye(3) + 0.02 * rng.normal(size=(n, 3, 3))).astype(np.float32)
+    dt = sc["dt"]
+    o = make_oracle(sc, "f64")
+    o.field("v")[:] = v0; o.field("F_trial")[:] = Ft0
+    o.phase("zero_grid"); o.phase("pre_p2g", dt); o.phase("compute_stress", dt); o.phase("p2g", dt)
+    o.phase("grid_update", dt); o.phase("grid_damping"); o.phase("apply_bcs", dt)
+    gv_o, m_o = o.field("grid_v_out").astype(np.float64), o.field("grid_m").astype(np.float64)
+    m_light = float(o.field("mass")[light].max())
+    # nodes that carry mass on the scale of LIGHT particles only (the heavy half does not reach them)
+    sel = (m_o > 1e-2 * m_light) & (m_o < 20 * m_light)
+    assert sel.sum() > 500
+    errs = {}
+    for mode in (0, 32, 64):
+        h = make_hip(sc)
+        h._set_scalar("scatter_bits", mode)
+        h.set_field("v", v0); h.set_field("F_trial", Ft0.reshape(n, 9))
+        h.phase(0, dt); h.phase(1, dt)
+        errs[mode] = (rel_l2(get(h, "grid_v_out").astype(np.float64)[sel], gv_o[sel]), h.scatter_bits, h._get_scalar("mass_contrast"))
+    print("light-side grid_v_out vs the float64 oracle:", {k: f"{v[0]:.2e} (mode {v[1]}, contrast {v[2]:.3g})" for k, v in errs.items()})
+    assert errs[0][1] == 64 and errs[0][2] > 5e3                  # auto picked the exact mode
+    assert errs[0][0] < 1e-4 and errs[64][0] < 1e-4
+    assert errs[32][0] > 3 * errs[64][0]                          # the packed mode's documented limit
+    uniform = make_hip(mpm_ball_scene(8000, seed=5))
+    uniform.run(dt, 2)
+    assert uniform.scatter_bits == 32 and uniform._get_scalar("mass_contrast") < 32
+
+
 def test_packed_scatter_parity(hip_device):
     """set_scalar "scatter_bits" 32: two 32-bit fixed-point sums per LDS atomic (2 atomics per node instead of 4).  The sums
     stay exact integers (bit-reproducible), the quantum grows from 2^-42 to 2^-22 of the largest contribution bound in a
