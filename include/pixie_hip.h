@@ -31,12 +31,7 @@ extern "C" {
 const char* pixie_last_error(void);
 /* Library/version probe: returns the gfx arch string the kernels were compiled for. */
 const char* pixie_build_arch(void);
-/* Tuning switches (process-wide).  "conv_wave_specialised" (default 0, experimental): 3^3 f16x3 layers with >= 256
- * workgroups run with 512-thread workgroups, four MFMA waves + four staging waves over a double-buffered LDS tile.
- * "conv_pipeline" (default 0): let 3^3 f16x3 layers with >= 512 workgroups use the
- * experimental software-pipelined kernel (one workgroup per CU, double-buffered LDS) instead of the
- * two-workgroups-per-CU kernel; both produce bit-identical results.  "conv_dbg": timing experiments only. */
-int pixie_set_option(const char* key, int value);
+/* (No process-wide switches: every option lives on a handle -- pixie_unet_set_option, pixie_mpm_set_scalar.) */
 
 /* ======================================================================================
  * (B) MLS-MPM solver -- replaces PG/mpm_solver_warp/mpm_solver_warp.py: MPM_Simulator_WARP

@@ -81,7 +81,6 @@ _D3 = C.POINTER(C.c_double)
 SIGNATURES = {
     "pixie_last_error": (C.c_char_p, []),
     "pixie_build_arch": (C.c_char_p, []),
-    "pixie_set_option": (_I, [_S, _I]),
     "pixie_mpm_create": (_I, [C.POINTER(_VP), _I, _I, _D]),
     "pixie_mpm_destroy": (_I, [_VP]),
     "pixie_mpm_regrid": (_I, [_VP, _I, _D, _VP]),

@@ -41,12 +41,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kW16HeaderU4 = 4;  // 64-byte header in front of the packed planes: [0].x = bits of 1/s_w
 
-// Phase trace for timing studies (conv_dbg bit 2): per workgroup 16 x 64-bit words -- 100 MHz timestamps at start, after each
-// chunk's staging barrier, after each chunk's MFMA phase, at the end; word 15 = HW_ID | XCC_ID << 32.  Read back with
-// pixie::conv_trace_read (not part of the C ABI).
-constexpr int kTraceWGs = 8192, kTraceWords = 16;
-__device__ unsigned long long g_conv_trace[kTraceWGs * kTraceWords];
-
 struct Conv16Args {
     const float* in0; const float* in1;
     int c0, cin;
@@ -78,8 +72,6 @@ struct Conv16Args {
     int sk_c0, sk_cin;
     const uint4* sk_w16; const float* sk_bias;
     const unsigned* sk_amax0; const unsigned* sk_amax1;
-    int dbg;                 // timing experiments only (pixie_set_option "conv_dbg"): 1 = A fragments always from tap 0, 2 = stage chunk 0 only,
-                             // 4 = phase trace, 32 = one workgroup per CU, 64 = 18 of 27 taps, 128 = every chunk staged twice, bits 8.. = start stagger in us
 };
 
 __device__ __forceinline__ int fast_div16(int n, int d, unsigned magic) {
@@ -100,39 +92,28 @@ __device__ __forceinline__ int scale_exponent(float bound) {
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
-// WS is EXPERIMENTAL and OFF BY DEFAULT (pixie_set_option("conv_wave_specialised", 1) / PIXIE_CONV_WS=1): bit-identical,
-// but a single MFMA wave per SIMD sustains only about a third of the matrix pipe in this loop (its per-tap A-fragment
-// and B-fragment latencies are exposed), so the layer takes 1.95 ms instead of 1.54 ms.
-// WS ("wave-specialised", 512 threads, one workgroup per CU): waves 0-3 run the MFMA loop of chunk c out of one LDS
-// buffer while waves 4-7 -- one per SIMD, next to a compute wave -- stage chunk c+1 into the other, so the loads,
-// the prologue arithmetic and the LDS writes are scheduled by the hardware into the gaps of the matrix pipe instead
-// of stopping it between chunks.  Without WS (256 threads) two workgroups share a CU and overlap only by chance.
+// One tiled body, two arithmetic variants.  256 threads = 4 waves; two workgroups share a CU (their staging and MFMA phases
+// overlap by occupancy).  Rejected and removed after measurement (profiles/README.md r1w): a wave-specialised
+// 512-thread variant (4 MFMA + 4 staging waves: 1.95 vs 1.54 ms) and a software-pipelined one-workgroup-per-CU variant
+// (1.74-1.89 vs 1.59 ms); the timing-study switches that used to live in the tap loop are gone with them.
 // EX ("exact"): the same tiling, staging, prologue and epilogue with fp32 operands on v_mfma_f32_32x32x2_f32 -- every product
 // and every accumulation in fp32, as the reference's cuDNN/PyTorch fp32 convolution computes them (conv_precision = "f32").
 // The LDS tile holds the 16 channels of a chunk as fp32 planes [channel][voxel] (the same 64 bytes per voxel as the four
 // fp16 planes), a lane's B operand is one conflict-free ds_read_b32, its A operand one coalesced 4-byte load from the
 // [tap][c_in][c_out] weight array (L2-resident: 442 KB for the 64 -> 64 layer), fetched one tap ahead.
-template <int KS, int MB, int NB, bool WS, bool EX = false>
+template <int KS, int MB, int NB, bool EX = false>
 __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     extern __shared__ uint4 smem16[];
     constexpr int PAD = (KS == 3) ? 1 : 0;
-    constexpr int NT = WS ? 512 : 256;
+    constexpr int NT = 256;
     const int bufsz = 4 * A.CS;            // one buffer: hi[2][CS], lo[2][CS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = (tid >> 6) & 3;       // position among the 4 compute waves (loader waves never use it)
-    const bool loader = WS && tid >= 256;
+    const int wave = tid >> 6;
     const int kh = lane >> 5;
     const int l31 = lane & 31;
 
-    if ((A.dbg >> 8) > 0 && blockIdx.x < 512u) {   // timing experiment: the odd-slot workgroups of the first round start (dbg >> 8) us late
-        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | 4);
-        if (hw_id & 1u) {
-            const unsigned long long t_start = wall_clock64();
-            while (wall_clock64() - t_start < (unsigned long long)(A.dbg >> 8) * 100ull) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     // XCD-aware tile order: consecutive workgroups go to different XCDs (b % 8), so give each XCD a contiguous
     // run of tiles -- neighbouring tiles then share their halo planes in that XCD's L2.
     int t = blockIdx.x;
@@ -343,15 +324,14 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
             ah[mb] = __builtin_bit_cast(f16x8, wh[mb * 32]);
             al[mb] = __builtin_bit_cast(f16x8, wl[mb * 32]);
         }
-        const int zy_end = (KS == 3 && (A.dbg & 64)) ? 6 : KS * KS;   // timing experiment: 18 of 27 taps (the MFMA count of a 1-D Winograd F(2,3))
 #pragma unroll 1
-        for (int zy = 0; zy < zy_end; ++zy) {
+        for (int zy = 0; zy < KS * KS; ++zy) {
             const int dz = zy / KS, dy = zy - dz * KS;
             const int rowoff = (dz * A.HY + dy) * A.HX;
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
                 const int tap = zy * KS + dx;
-                const int nxt = (A.dbg & 1) ? 0 : ((tap + 1 < TAPS) ? tap + 1 : tap);   // last tap: re-read itself (harmless)
+                const int nxt = (tap + 1 < TAPS) ? tap + 1 : tap;   // last tap: re-read itself (harmless)
                 f16x8 ahn[MB], aln[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
@@ -392,34 +372,14 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     };
 
     float inv2 = 0.0f;   // unscale factor after a folded skip convolution
-    if (WS) {
-        stage_chunk(0, smem16, tid, NT);     // everybody stages chunk 0
-        __syncthreads();
-        int par = 0;
-        for (int c_base = 0; c_base < A.cin; c_base += 16, par ^= 1) {
-            if (loader) {
-                if (c_base + 16 < A.cin) stage_chunk(c_base + 16, smem16 + (par ^ 1) * bufsz, tid - 256, 256);
-            } else {
-                mfma_chunk(c_base, smem16 + par * bufsz);
-            }
-            __syncthreads();   // buffer `par` fully consumed, buffer `par ^ 1` fully written
-        }
-        if (loader) return;
-    } else {
+    {
         const int c_begin = A.partial ? (int)blockIdx.z * A.chunks_per_slice * 16 : 0;
         const int c_end = A.partial ? min(A.cin, c_begin + A.chunks_per_slice * 16) : A.cin;
-        const bool trace = (A.dbg & 4) && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < (unsigned)kTraceWGs;
-        unsigned long long* tr = g_conv_trace + (size_t)blockIdx.x * kTraceWords;
-        int ti = 0;
-        if (trace) tr[ti++] = wall_clock64();
         for (int c_base = c_begin; c_base < c_end; c_base += 16) {
             __syncthreads();  // previous chunk fully consumed
-            if (!((A.dbg & 2) && c_base > c_begin)) stage_chunk(c_base, smem16, tid, NT);
-            if (A.dbg & 128) { __syncthreads(); stage_chunk(c_base, smem16, tid, NT); }   // timing experiment: staging costs twice
+            stage_chunk(c_base, smem16, tid, NT);
             __syncthreads();
-            if (trace && ti < 13) tr[ti++] = wall_clock64();
             mfma_chunk(c_base, smem16);
-            if (trace && ti < 13) tr[ti++] = wall_clock64();
         }
         if (!EX && A.sk_w16) {
             // ---- the block's 1x1x1 skip convolution, in the same accumulators (so that out = conv(h) + skip(x) leaves this
@@ -502,10 +462,6 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
             }
         }
-        if (trace) {
-            tr[13] = ti;
-            tr[15] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-        }
     }
 
     // ---- epilogue: unscale, + bias (+ residual); C/D layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -513,7 +469,7 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     // registers: per output channel the sum and sum of squares over this workgroup's voxels (lane -> 32-lane DPP
     // reduction -> 4 waves through LDS) go to stats[tile][c_out_padded][2] with plain stores, and the tile's |x|max
     // to *out_amax; pixie_stats_finalize adds the tiles up in fp64.  That replaces one full read of the tensor.
-    const float inv = EX ? 1.0f : ((!WS && A.sk_w16) ? inv2 : __uint_as_float(A.w16[0].x) * pow2i(-ex));
+    const float inv = EX ? 1.0f : (A.sk_w16 ? inv2 : __uint_as_float(A.w16[0].x) * pow2i(-ex));
     if (A.partial) {   // split-K slice: raw partial sums; bias, residual and statistics belong to splitk_reduce_kernel
         float* dst = A.partial + (size_t)blockIdx.z * A.cout * OSP;
 #pragma unroll
@@ -623,24 +579,22 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
             if (lane == 0 && wmax > 0.0f) atomicMax(A.out_amax, __float_as_uint(wmax));
         }
     }
-    if (!WS && (A.dbg & 4) && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < (unsigned)kTraceWGs)
-        g_conv_trace[(size_t)blockIdx.x * kTraceWords + 14] = wall_clock64();
 }
 
-template <int KS, int MB, int NB, bool WS>
-__global__ __launch_bounds__(WS ? 512 : 256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
-    conv3d_f16x3_body<KS, MB, NB, WS>(A);
+template <int KS, int MB, int NB>
+__global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
+    conv3d_f16x3_body<KS, MB, NB>(A);
 }
 // conv_precision = "f32": the exact-fp32 variant of the same body (v_mfma_f32_32x32x2_f32)
 template <int KS, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv3d_exact_kernel(Conv16Args A) {
-    conv3d_f16x3_body<KS, MB, NB, false, true>(A);
+    conv3d_f16x3_body<KS, MB, NB, true>(A);
 }
 // The dominant layer of the BASELINE network -- 64 -> 64 channels, 3^3, stride 1, on >= 128^3 voxels (the full-resolution
 // level: 41 % of a scene's FLOPs at 128^3; the 64^3 level has the same channel counts and stays on the template) -- under its own symbol, so that `rocprofv3 --kernel-trace --stats` reports it as
 // its own row instead of pooling it with the other shapes that share the <3,2,4> instantiation.  Same code, same results.
 __global__ __launch_bounds__(256, 2) void conv3d_f16x3_c64_fullres_kernel(Conv16Args A) {
-    conv3d_f16x3_body<3, 2, 4, false>(A);
+    conv3d_f16x3_body<3, 2, 4>(A);
 }
 
 // stats[tile][coutp][2] (fp32, from the conv epilogues) -> sums[c][2] (fp64), one workgroup per channel
@@ -668,289 +622,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (bias) v += bias[i / osp];
     if (residual) v += residual[i];
     out[i] = v;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL, OFF BY DEFAULT (pixie_set_option("conv_pipeline", 1) / PIXIE_CONV_PIPE=1): bit-identical to the kernel
-// above, measured 1.74-1.89 ms against its 1.59 ms on the 64->64 3^3 128^3 layer (profiles/README.md) -- with one wave
-// per SIMD the compiler's interleaving of the staging VALU work between the MFMAs does not make up for losing the
-// second workgroup's overlap.  Kept, with its bit-identity test, as the starting point for a hand-scheduled version.
-//
-// Software-pipelined variant for the 3^3 layers that dominate the network (KS = 3): ONE workgroup per CU (one wave per
-// SIMD, so up to 512 registers per lane), the activation tile double-buffered in LDS (2 x 78 KB), and the staging of
-// chunk c+1 -- global loads, prologue, fp16 split, LDS writes -- spread over the first taps of chunk c, one 8-channel
-// unit per tap, so that it issues in the shadow of that tap's 24 MFMAs (32 cycles each on the SIMD's matrix pipe)
-// instead of stopping all four waves between chunks.  A fragments of tap t+1 are fetched during tap t.
-// The staging code is branch-free (template flags instead of null checks, clamped addresses and a dummy LDS slot
-// instead of bounds branches) so that it lives in the same basic block as the MFMAs and the scheduler can interleave it.
-struct StageRegs {
-    float val[8];
-    float gm, bt;
-    int slot;      // 16-byte LDS slot ([kg][voxel]) this unit is written to; the dummy slot when the unit does not exist
-    int kg;        // which half of the chunk's 16 channels
-    float sxe;     // input scale, or 0 outside the (logical) input volume: zero padding applied AFTER the activation
-};
-
-template <int MB, int NB, bool PRO, bool AFF, int ACT>
-__global__ __launch_bounds__(256, 1) void conv3d_f16x3_pipe_kernel(Conv16Args A) {
-    extern __shared__ uint4 smem16[];
-    constexpr int KS = 3, PAD = 1, TAPS = 27;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int kh = lane >> 5;
-    const int l31 = lane & 31;
-
-    int t = blockIdx.x;
-    {
-        const int per = (A.n_tiles + 7) >> 3;
-        if ((A.n_tiles & 7) == 0) t = (t & 7) * per + (t >> 3);   // XCD-contiguous tile runs (see the kernel above)
-    }
-    const int tx = t % A.tiles_x; t /= A.tiles_x;
-    const int ty = t % A.tiles_y;
-    const int tz = t / A.tiles_y;
-    const int ox0 = tx * A.TX, oy0 = ty * A.TY, oz0 = tz * A.TZ;
-    const int cout0 = blockIdx.y * (MB * 32);
-    const int lx0 = ox0 - PAD, ly0 = oy0 - PAD, lz0 = oz0 - PAD;
-    const size_t ISP = (size_t)A.ID * A.IH * A.IW;
-    const size_t OSP = (size_t)A.OD * A.OH * A.OW;
-
-    int voff[NB];
-    int ovox[NB];
-    bool valid[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int j = (wave * NB + nb) * 32 + l31;
-        int x = j & (A.TX - 1);
-        int y = (j >> A.lTX) & (A.TY - 1);
-        int z = j >> (A.lTX + A.lTY);
-        const bool v = (z < A.TZ) && (ox0 + x < A.OW) && (oy0 + y < A.OH) && (oz0 + z < A.OD);
-        if (!v) { x = 0; y = 0; z = 0; }
-        voff[nb] = (z * A.HY + y) * A.HX + x + kh * A.CS;
-        ovox[nb] = ((oz0 + z) * A.OH + (oy0 + y)) * A.OW + ox0 + x;
-        valid[nb] = v;
-    }
-
-    float bound = A.in_bound;
-    if (A.amax0) {
-        bound = __uint_as_float(*A.amax0);
-        if (A.amax1) bound = fmaxf(bound, __uint_as_float(*A.amax1));
-    }
-    const int ex = scale_exponent(bound);
-    const float sx = pow2i(ex);
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
-
-    const int KG = A.cin >> 3;
-    const size_t tap_stride = (size_t)KG * A.coutp;
-    const size_t plane = (size_t)TAPS * tap_stride;
-    const uint4* wHi = A.w16 + kW16HeaderU4 + (size_t)kh * A.coutp + cout0 + l31;
-    const uint4* wLo = wHi + plane;
-    const float* wF = A.wf + (size_t)kh * A.coutp + cout0 + l31;     // EX: channel (2 kp + kh) of the pair, row l31 of block mb
-
-    const int nunits = 2 * A.CS;                 // 16-byte units per chunk: [kg 0..1][voxel]
-    const int upt = (nunits + 255) >> 8;         // units per thread (10 for the 32x4x4 tile)
-    const int half = 2 * A.CS + 1;               // uint4 per hi (or lo) plane of one buffer, + 1 dummy slot
-    const int bufsz = 2 * half;
-
-    // issue the loads of unit (k*256 + tid) of the chunk starting at channel c_base (no branches: see above)
-    auto stage_load = [&](int k, int c_base, StageRegs& r) {
-        const int it = k * 256 + tid;
-        const bool exists = it < nunits;
-        const int kg = (it >= A.CS) ? 1 : 0;
-        int rem = exists ? it - kg * A.CS : 0;
-        const int hz = (int)__umulhi((unsigned)rem, A.mHYX);   // HYX, HX >= 3 here: the magic multipliers are valid
-        rem -= hz * A.HYX;
-        const int hy = (int)__umulhi((unsigned)rem, A.mHX);
-        const int hx = rem - hy * A.HX;
-        const int lz = lz0 + hz, ly = ly0 + hy, lx = lx0 + hx;
-        const bool inb = exists && (unsigned)lz < (unsigned)A.LD && (unsigned)ly < (unsigned)A.LH && (unsigned)lx < (unsigned)A.LW;
-        r.sxe = inb ? sx : 0.0f;
-        r.slot = exists ? it : 2 * A.CS;
-        r.kg = kg;
-        // clamped coordinates: always a valid address, no branch; the value is multiplied by sxe = 0 when outside
-        const int cz = min(max(lz, 0), A.LD - 1), cy = min(max(ly, 0), A.LH - 1), cx = min(max(lx, 0), A.LW - 1);
-        const int sidx = ((cz >> A.ups) * A.IH + (cy >> A.ups)) * A.IW + (cx >> A.ups);
-        const int cg0 = c_base + kg * 8;
-        const float* src = (cg0 < A.c0) ? (A.in0 + (size_t)cg0 * ISP) : (A.in1 + (size_t)(cg0 - A.c0) * ISP);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.val[j] = src[(size_t)j * ISP + sidx];
-        if (AFF) { r.gm = A.gamma[sidx]; r.bt = A.beta[sidx]; }
-    };
-    // prologue + fp16 split + LDS write of a loaded unit into the buffer whose hi plane starts at `buf`
-    float pa[16], pb[16];   // per-channel prologue constants of the chunk being staged (uniform: scalar loads)
-    auto load_pro = [&](int c_base) {
-        if (PRO) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { pa[j] = A.pro_a[c_base + j]; pb[j] = A.pro_b[c_base + j]; }
-        }
-    };
-    auto stage_convert = [&](const StageRegs& r, f16x8& vh, f16x8& vl) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float tv = r.val[j];
-            if (PRO) tv = tv * (r.kg ? pa[8 + j] : pa[j]) + (r.kg ? pb[8 + j] : pb[j]);
-            if (AFF) tv = tv * r.gm + r.bt;
-            if (ACT == 1) tv = fmaxf(tv, 0.02f * tv);
-            if (ACT == 2) tv = tv / (1.0f + __expf(-tv));
-            const float sc = tv * r.sxe;
-            const _Float16 h = (_Float16)sc;
-            vh[j] = h;
-            vl[j] = (_Float16)(sc - (float)h);
-        }
-    };
-    auto stage_store = [&](const StageRegs& r, uint4* buf) {
-        f16x8 vh, vl;
-        stage_convert(r, vh, vl);
-        buf[r.slot] = __builtin_bit_cast(uint4, vh);
-        buf[half + r.slot] = __builtin_bit_cast(uint4, vl);
-    };
-
-    // ---- chunk 0 is staged up front ----
-    load_pro(0);
-    for (int k = 0; k < upt; ++k) {
-        StageRegs r;
-        stage_load(k, 0, r);
-        stage_store(r, smem16);
-    }
-    __syncthreads();
-
-    // one tap: [staging micro-step for the next chunk] + prefetch of the NEXT tap's A (L2) and B (LDS) fragments +
-    // 24 MFMAs on the current ones; the sched_group_barriers spread the memory ops and the VALU work between the MFMAs
-    f16x8 ah[MB], al[MB], bh[NB], bl[NB];
-    constexpr int RING = 4;   // a unit's loads are consumed RING taps (~3000 cycles) after they were issued
-    StageRegs ring[RING];
-    auto tap_body = [&](auto stage_tag, int tap, int tapoff_next, const uint4* cur, uint4* nxt, const uint4* wh, const uint4* wl, int c_next,
-                        StageRegs& sr) {
-        constexpr bool STAGE = decltype(stage_tag)::value;
-        StageRegs nw;
-        if (STAGE) stage_load(tap, c_next, nw);   // tap >= upt: nothing left, becomes the dummy unit
-        const int nt = (tap + 1 < TAPS) ? tap + 1 : tap;
-        f16x8 ahn[MB], aln[MB], bhn[NB], bln[NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            ahn[mb] = __builtin_bit_cast(f16x8, wh[(size_t)nt * tap_stride + mb * 32]);
-            aln[mb] = __builtin_bit_cast(f16x8, wl[(size_t)nt * tap_stride + mb * 32]);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            bhn[nb] = __builtin_bit_cast(f16x8, cur[voff[nb] + tapoff_next]);
-            bln[nb] = __builtin_bit_cast(f16x8, cur[half + voff[nb] + tapoff_next]);
-        }
-        f16x8 vh, vl;
-        if (STAGE) stage_convert(sr, vh, vl);     // the unit loaded RING taps ago (first RING taps: the dummy unit)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
-        if (STAGE) {
-            nxt[sr.slot] = __builtin_bit_cast(uint4, vh);
-            nxt[half + sr.slot] = __builtin_bit_cast(uint4, vl);
-            sr = nw;
-        }
-        // issue order: one MFMA, then what fits in its 32-cycle shadow
-#pragma unroll
-        for (int i = 0; i < 3 * MB * NB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one B-fragment read
-            if (i < 2 * MB + (STAGE ? 10 : 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one global load
-            __builtin_amdgcn_sched_group_barrier(0x002, STAGE ? 7 : 2, 0);
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) { ah[mb] = ahn[mb]; al[mb] = aln[mb]; }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { bh[nb] = bhn[nb]; bl[nb] = bln[nb]; }
-    };
-
-    const int nchunks = A.cin >> 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const int c_base = c << 4;
-        const uint4* cur = smem16 + (c & 1) * bufsz;
-        uint4* nxt = smem16 + ((c & 1) ^ 1) * bufsz;
-        const uint4* wh = wHi + (size_t)(c_base >> 3) * A.coutp;
-        const uint4* wl = wLo + (size_t)(c_base >> 3) * A.coutp;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            ah[mb] = __builtin_bit_cast(f16x8, wh[mb * 32]);
-            al[mb] = __builtin_bit_cast(f16x8, wl[mb * 32]);
-        }
-        // staged taps: unit k is loaded at tap k and written to LDS at tap k + RING; none for the last chunk
-        const int n_groups = (c + 1 < nchunks) ? (upt + RING + RING - 1) / RING : 0;
-        const int n_staged = min(n_groups * RING, TAPS / RING * RING);
-        if (n_staged) load_pro(c_base + 16);
-#pragma unroll
-        for (int u = 0; u < RING; ++u) {
-            ring[u].slot = 2 * A.CS; ring[u].sxe = 0.0f; ring[u].kg = 0; ring[u].gm = 1.0f; ring[u].bt = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ring[u].val[j] = 0.0f;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {   // B fragments of tap 0 (every later tap's are prefetched one tap ahead)
-            bh[nb] = __builtin_bit_cast(f16x8, cur[voff[nb]]);
-            bl[nb] = __builtin_bit_cast(f16x8, cur[half + voff[nb]]);
-        }
-        int dx = 0, dy = 0, tapoff = 0;
-        auto advance = [&](int tap) {   // LDS offset of the tap after `tap`
-            int tn = tapoff + 1;
-            if (++dx == KS) { dx = 0; tn += A.HX - KS; if (++dy == KS) { dy = 0; tn += (A.HY - KS) * A.HX; } }
-            return (tap == TAPS - 1) ? tapoff : tn;   // nothing after the last tap of a chunk: re-read (discarded)
-        };
-        // two separate loops (not one loop with a branch): the accumulators must not pass through a phi
-#pragma unroll 1
-        for (int t0 = 0; t0 < n_staged; t0 += RING) {
-#pragma unroll
-            for (int u = 0; u < RING; ++u) {
-                const int tn = advance(t0 + u);
-                tap_body(std::true_type{}, t0 + u, tn, cur, nxt, wh, wl, c_base + 16, ring[u]);
-                tapoff = tn;
-            }
-        }
-#pragma unroll 1
-        for (int tap = n_staged; tap < TAPS; ++tap) {
-            const int tn = advance(tap);
-            tap_body(std::false_type{}, tap, tn, cur, nxt, wh, wl, c_base + 16, ring[0]);
-            tapoff = tn;
-        }
-        __syncthreads();   // every wave is done reading `cur` and writing `nxt`
-    }
-
-    const float inv = __uint_as_float(A.w16[0].x) * pow2i(-ex);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cout0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co < A.cout) {
-                const float bv = (A.bias ? A.bias[co] : 0.0f) + (A.sk_bias ? A.sk_bias[co] : 0.0f);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if (valid[nb]) {
-                        const size_t o = (size_t)co * OSP + ovox[nb];
-                        float val = acc[mb][nb][r] * inv + bv;
-                        if (A.residual) val += A.residual[o];
-                        A.out[o] = val;
-                    }
-                }
-            }
-        }
-    }
 }
 
 // |x|max of a tensor as float bits (non-negative floats order like unsigned integers); caller zeroes the slot
@@ -1002,16 +673,15 @@ static unsigned magic_of16(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000
 static int ilog2_16(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static int pow2_le16(int v, int cap) { int p = 1; while (p * 2 <= v && p * 2 <= cap) p *= 2; return p; }
 
-template <int KS, int MB, int NB, bool WS = false>
+template <int KS, int MB, int NB>
 static int launch_f16x3(const Conv16Args& a, size_t lds_bytes, dim3 grid, hipStream_t st) {
-    auto kern = conv3d_f16x3_kernel<KS, MB, NB, WS>;
+    auto kern = conv3d_f16x3_kernel<KS, MB, NB>;
     PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
-    hipLaunchKernelGGL(kern, grid, dim3(WS ? 512 : 256), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-static int g_conv_force_nb = 0;   // timing experiments (pixie_set_option "conv_force_nb"): 1, 2 or 4 voxel blocks per wave; 0 = heuristic
 // geometry + tile selection shared by the launcher, pixie_conv_stats_floats and pixie_stats_finalize
 static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, int& NB_out, int* slices_out = nullptr) {
     a.ID = d->in_d; a.IH = d->in_h; a.IW = d->in_w;
@@ -1049,7 +719,6 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
         if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
     }
     if (slices_out) *slices_out = slices;
-    if (g_conv_force_nb > 0 && slices == 1 && a.stride == 1) NB = g_conv_force_nb;
 
     const int tile_vox = 128 * NB;
     a.TX = pow2_le16(a.OW, 32);
@@ -1064,14 +733,6 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
 
     MB_out = MB; NB_out = NB;
 }
-
-static int g_conv_dbg = 0;
-int conv_trace_read(unsigned long long* host, int n_words) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), (size_t)n_words * sizeof(unsigned long long));
-}
-static bool g_conv_ws = getenv("PIXIE_CONV_WS") != nullptr;   // measured slower on MI355X (1.95 vs 1.54 ms): off by default
-static bool g_conv_no_pipe = getenv("PIXIE_CONV_PIPE") == nullptr;   // measured slower on MI355X (see header): off by default
-void conv_set_pipe(bool on) { g_conv_no_pipe = !on; }
 
 // called by pixie_conv3d_forward (conv3d_mfma.hip) when the descriptor carries f16x2-packed weights
 int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
@@ -1095,7 +756,6 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     a.w16 = reinterpret_cast<const uint4*>(d->d_w16); a.bias = d->d_bias; a.cout = d->c_out; a.coutp = pixie_conv_cout_padded(d->c_out);
     a.residual = d->d_residual; a.out = d->d_out;
     a.amax0 = d->d_in_amax0; a.amax1 = (d->c1 > 0) ? d->d_in_amax1 : nullptr; a.in_bound = d->in_bound;
-    a.dbg = g_conv_dbg;
     a.stats = d->d_out_stats; a.out_amax = d->d_out_amax;
 
     int MB = 0, NB = 0, slices = 1;
@@ -1120,7 +780,6 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
         const size_t epi = ((size_t)4 * 32 * (NB * 32 + 4) + (size_t)4 * MB * 32 * 2) * sizeof(float);
         if (slices == 1 && epi <= 80 * 1024) { a.epi_lds = 1; if (lds < epi) lds = epi; }
     }
-    if ((g_conv_dbg & 32) && lds < 100 * 1024) lds = 100 * 1024;   // timing experiment: one workgroup per CU
     const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)), (unsigned)slices);
     if (slices > 1) {
         int rc = 1;
@@ -1136,28 +795,6 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
         PX_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    // the software-pipelined kernel: 3^3, full 64 x 512 workgroup tile, double-buffered LDS must fit, > 1 chunk,
-    // and enough workgroups that one per CU still fills the chip
-    const bool no_pipe = g_conv_no_pipe;
-    const size_t lds_pipe = 2 * (lds + 2 * sizeof(uint4));   // two buffers, each with a dummy slot per plane
-    if (!no_pipe && !a.sk_w16 && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && lds_pipe <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 512) {
-        const bool pro = d->d_pro_a != nullptr, aff = d->d_gamma != nullptr;
-        const void* kern = nullptr;
-        if (pro && aff && d->act == 1) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, true, 1>);
-        else if (!pro && !aff && d->act == 0) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, false, false, 0>);
-        else if (pro && !aff && d->act == 2) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, false, 2>);
-        else if (pro && !aff && d->act == 0) kern = reinterpret_cast<const void*>(conv3d_f16x3_pipe_kernel<2, 4, true, false, 0>);
-        if (kern) {
-            PX_CHECK_HIP(allow_max_dynamic_lds(kern));
-            void* args[] = {const_cast<Conv16Args*>(&a)};
-            PX_CHECK_HIP(hipLaunchKernel(kern, grid, dim3(256), args, lds_pipe, st));
-            return 0;
-        }
-    }
-    // wave-specialised variant: the full 64 x 512 tile of a 3^3 layer, both LDS buffers fit, and at least one
-    // workgroup per CU
-    if (g_conv_ws && !a.sk_w16 && !a.stats && d->ksize == 3 && MB == 2 && NB == 4 && 2 * lds <= 160 * 1024 && cin >= 32 && (long)grid.x * grid.y >= 256)
-        return launch_f16x3<3, 2, 4, true>(a, 2 * lds, grid, st);
     if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 && !a.sk_w16 &&
         (long)a.OD * a.OH * a.OW >= 128L * 128 * 128) {
         auto kern = conv3d_f16x3_c64_fullres_kernel;
@@ -1200,7 +837,6 @@ int conv3d_exact_forward(const pixie_conv_desc* d, hipStream_t st) {
     a.wf = d->d_w; a.bias = d->d_bias;
     a.residual = d->d_residual; a.out = d->d_out;
     a.in_bound = 1.0f;
-    a.dbg = 0;
     pixie_conv_desc probe = *d;
     probe.d_workspace = nullptr;            // no split-K on this path: small layers shrink the tile instead
     int MB = 0, NB = 0, slices = 1;
@@ -1225,15 +861,6 @@ int conv3d_exact_forward(const pixie_conv_desc* d, hipStream_t st) {
 }  // namespace pixie
 
 using namespace pixie;
-
-extern "C" int pixie_set_option(const char* key, int value) {
-    PX_REQUIRE(key, "pixie_set_option: null key");
-    if (std::string(key) == "conv_pipeline") { conv_set_pipe(value != 0); return 0; }
-    if (std::string(key) == "conv_dbg") { g_conv_dbg = value; return 0; }
-    if (std::string(key) == "conv_force_nb") { PX_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "conv_force_nb: 0, 1, 2 or 4"); g_conv_force_nb = value; return 0; }
-    if (std::string(key) == "conv_wave_specialised") { g_conv_ws = value != 0; return 0; }
-    return set_error("pixie_set_option: unknown key '%s'", key);
-}
 
 // number of floats of the epilogue statistics buffer for this descriptor (0 if the layer does not take the f16x3 path)
 extern "C" int64_t pixie_conv_stats_floats(const pixie_conv_desc* d) {

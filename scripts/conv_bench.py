@@ -29,10 +29,6 @@ def main():
     ops = HipOps(dev)
     g = torch.Generator().manual_seed(0)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    if os.environ.get("PIXIE_CONV_FORCE_NB"):
-        ops.lib.pixie_set_option(b"conv_force_nb", int(os.environ["PIXIE_CONV_FORCE_NB"]))
-    if os.environ.get("PIXIE_CONV_DBG"):
-        ops.lib.pixie_set_option(b"conv_dbg", int(os.environ["PIXIE_CONV_DBG"]))
     nshapes = int(os.environ.get("PIXIE_CONV_NSHAPES", len(SHAPES)))
     for cins, cout, D, k, ups, prologue in SHAPES[:nshapes]:
         cin = sum(cins)

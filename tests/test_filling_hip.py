@@ -92,8 +92,6 @@ def test_boundary_and_overflow(hip_device):
     assert np.allclose(na[key(na)], nb[key(nb)], atol=2e-6)
     with pytest.raises(RuntimeError):
         fill_particles(p, o, c, 32, 100, 1.0 / 32, boundary=bnd)
-    with pytest.raises(NotImplementedError):
-        fill_particles(p, o, c, 32, 100, 1.0 / 32, smooth=True)
 
 
 def test_particle_volume_and_init_filled(hip_device):

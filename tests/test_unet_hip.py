@@ -179,11 +179,12 @@ def test_conv3d_f16x3_layernorm_prologue_with_outlier_gamma(ops, outlier):
 
 
 @pytest.mark.parametrize("variant", ["ln_leaky", "raw", "gn_silu", "gn_none", "concat_ln"])
-def test_conv3d_kernel_variants_are_bit_identical(ops, variant):
-    """The three f16x3 kernels for the dominant 3^3 layers -- plain (2 workgroups per CU; the default), experimental
-    wave-specialised (4 MFMA waves + 4 staging waves, LDS double buffer) and experimental software-pipelined -- on a 64^3 grid
-    (512 workgroups): same MFMA order, so the outputs must agree bit for bit; and against a float64 reference on
-    sample blocks (corner, interior: halo and padding paths)."""
+def test_conv3d_prologue_variants_on_the_dominant_shape(ops, variant):
+    """The f16x3 kernel on the dominant 3^3 64-channel shape (64^3 grid, 512 workgroups) under every prologue the network
+    uses -- LayerNorm affine + LeakyReLU, raw, GroupNorm + SiLU, GroupNorm alone, concatenated input -- twice (the result is
+    a pure function of the inputs: bit-identical) and against a float64 reference on sample blocks (corner, interior: halo
+    and padding paths).  (Until round 3 this test also held two experimental kernel families -- wave-specialised and
+    software-pipelined -- bit-identical to this one; both were measured slower and are removed.)"""
     from pixie_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(17)
@@ -214,14 +215,10 @@ def test_conv3d_kernel_variants_are_bit_identical(ops, variant):
         kw["in_bound"] = float(_prologue_cpu(parts, pro, affine, act).abs().max())
     w16 = ops.pack_conv16(to(w))
     outs = []
-    for ws, pipe in ((1, 0), (0, 1), (0, 0)):   # wave-specialised (default), experimental pipelined, plain
-        assert lib.pixie_set_option(b"conv_wave_specialised", ws) == 0
-        assert lib.pixie_set_option(b"conv_pipeline", pipe) == 0
+    for _ in range(2):
         outs.append(ops.conv(dparts, None, to(b), 64, 3, w16=w16, **kw))
-    lib.pixie_set_option(b"conv_wave_specialised", 0)
-    lib.pixie_set_option(b"conv_pipeline", 0)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[0], outs[1])
     # float64 spot check on a 6^3 corner block and a 6^3 interior block (halo and padding paths)
     x = _prologue_cpu(parts, pro, affine, act).double()
     xp = F.pad(x, (1, 1, 1, 1, 1, 1))
