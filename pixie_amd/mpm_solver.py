@@ -172,9 +172,9 @@ class MPM_Simulator_WARP:
         n = getattr(self, "_pending", 0)
         if n:
             self._pending = 0
-            stream = getattr(self, "_pending_stream", None) or self._stream     # the stream the substeps were queued under
+            queued = getattr(self, "_pending_stream", None)     # the stream the substeps were queued under (an integer handle)
             self._pending_stream = None
-            check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, stream), "pixie_mpm_step")
+            check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, self._stream if queued is None else C.c_void_p(queued)), "pixie_mpm_step")
             self._warn_if_particles_lost()
 
     def _get_scalar(self, key):
@@ -349,7 +349,7 @@ class MPM_Simulator_WARP:
         """:514-637 -- one substep.  Deferred: the substep is queued and runs, fused with its neighbours, when the
         solver is next observed or changed (module docstring); a change of dt flushes what was queued first."""
         dt = float(dt)
-        stream = self._stream
+        stream = self._stream.value or 0
         # a change of dt -- or of the CURRENT STREAM (ADVICE r3: a caller that wraps part of its loop in torch.cuda.stream(s)
         # must get its substeps on the stream they were issued under, not on whatever is current at flush time) -- ends a batch
         if self._pending and (dt != self._pending_dt or stream != self._pending_stream):
@@ -363,7 +363,7 @@ class MPM_Simulator_WARP:
     def run(self, dt, n_substeps):
         """n substeps of p2g2p in one call (fused G2P->P2G->grid launches, no host synchronisation)."""
         dt = float(dt)
-        stream = self._stream
+        stream = self._stream.value or 0
         if self._pending and (dt != self._pending_dt or stream != self._pending_stream):
             self.flush()
         self._pending_dt = dt

@@ -175,10 +175,11 @@ def fill_particles(pos, opacity, cov, grid_n: int, max_samples: int, grid_dx: fl
                                      _p(particles), int(max_samples), _p(counter), int(seed) & 0xFFFFFFFF, st), "pixie_fill_dense_cells")
     n_dense = int(counter.item())
     print("after dense grids: ", n_dense)
-    if smooth:    # filling.py:351-358: the density grid becomes the constrained-smoothed signed distance of its support
-        density = smooth_constrained(density, max_iters=500).to(torch.float32).contiguous()
+    search_field = density
+    if smooth:    # filling.py:351-358: the internal filling reads the constrained-smoothed signed distance of the density's support
+        search_field = smooth_constrained(density, max_iters=500).to(torch.float32).contiguous()
         print("smooth finished")
-    check(lib.pixie_fill_internal_cells(_p(count), _p(density), int(grid_n), float(grid_dx), int(max_particles_per_cell), int(search_exclude_dir),
+    check(lib.pixie_fill_internal_cells(_p(count), _p(search_field), int(grid_n), float(grid_dx), int(max_particles_per_cell), int(search_exclude_dir),
                                         int(ray_cast_dir), float(search_thres), _p(particles), int(max_samples), _p(counter),
                                         int(seed) & 0xFFFFFFFF, st), "pixie_fill_internal_cells")
     fill_num = int(counter.item())

@@ -284,6 +284,24 @@ def test_latency_optimised_variant_matches(hip_device):
     assert rel_l2(res[1]["v"], res[0]["v"]) < 1e-4
 
 
+def test_deferred_substeps_keep_the_stream_they_were_queued_on(hip_device):
+    """p2g2p() only queues; the batch must be enqueued on the stream that was current when it was queued, and a
+    change of the current stream ends the batch."""
+    sc = mpm_ball_scene(6000, seed=9)
+    a, b = make_hip(sc), make_hip(sc)
+    side = torch.cuda.Stream(hip_device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(5):
+            a.p2g2p(i, sc["dt"])
+        assert a._pending == 5 and a._pending_stream == side.cuda_stream
+    a.p2g2p(5, sc["dt"])                        # queued under another stream: the five above were flushed onto `side` first
+    assert a._pending == 1 and a._pending_stream == (torch.cuda.current_stream().cuda_stream or 0)
+    torch.cuda.current_stream().wait_stream(side)
+    b.run(sc["dt"], 6)
+    assert np.array_equal(get(a, "x"), get(b, "x")) and np.array_equal(get(a, "F_trial"), get(b, "F_trial"))
+
+
 def test_mass_contrast_selects_the_exact_scatter(hip_device):
     """the packed scatter's quantum is 2^-30 of the SUM of a work item's bounds, so nodes fed only by particles much
     lighter than their tile-mates are quantised at visible weights.  A scene whose upper half is 1e4 times lighter than its
