@@ -173,22 +173,31 @@ __device__ __forceinline__ void weights_1d(const Stencil& st, int d, Weights1D& 
 }
 
 // v = sum w g;  B_ab = sum w g_a dpos_b (cell units);  G_ab = sum g_a dweight_b (cell units)
+// Two contractions of every node value g_a(i,j,k) carry all 21 sums (6 FMAs per node instead of 9; 288 VALU instructions per
+// particle instead of 441 -- round 4, the kernel is VALU-issue bound):
+//   s_a(i,j) = sum_k wz_k g_a       -> the x- and y-derivative columns:  ss_a(i) = sum_j wy_j s_a,  t_a(j) = sum_i wx_i s_a
+//   h_a(k)   = sum_ij wx_i wy_j g_a -> v and the z-derivative column
+//   v_a = sum_k wz_k h_a(k);   G_a0 = sum_i dwx_i ss_a(i),  G_a1 = sum_j dwy_j t_a(j),  G_a2 = sum_k dwz_k h_a(k);   B likewise with wd.
 // SCHED: keep the loads of one x-slab from being hoisted over the previous slab's arithmetic (the 5-waves-per-SIMD register
 // budget needs it; the wide variant for small scenes, F_WIDE, lets the compiler overlap everything).
 template <bool SCHED, class Fetch>
 __device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float nv[3], Mat3& B, Mat3& G) {
     Weights1D wx, wy, wz;
     weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
+    float h[3][3], t[3][3], g0[3], b0[3];   // h[k][a], t[j][a]
 #pragma unroll
-    for (int a = 0; a < 3; ++a) nv[a] = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        g0[a] = 0.0f; b0[a] = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) { B.m[q] = 0.0f; G.m[q] = 0.0f; }
+        for (int o = 0; o < 3; ++o) { h[o][a] = 0.0f; t[o][a] = 0.0f; }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float ss[3] = {0, 0, 0}, ds[3] = {0, 0, 0}, ys[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, sz[3] = {0, 0, 0};
+        float ss[3] = {0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float s[3] = {0, 0, 0}, d[3] = {0, 0, 0}, z[3] = {0, 0, 0};
+            const float wij = wx.w[i] * wy.w[j];
+            float s[3] = {0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float g[3];
@@ -196,65 +205,69 @@ __device__ __forceinline__ void g2p_gather(const Stencil& st, Fetch fetch, float
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     s[a] = fmaf(wz.w[k], g[a], s[a]);
-                    d[a] = fmaf(wz.dw[k], g[a], d[a]);
-                    z[a] = fmaf(wz.wd[k], g[a], z[a]);
+                    h[k][a] = fmaf(wij, g[a], h[k][a]);
                 }
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 ss[a] = fmaf(wy.w[j], s[a], ss[a]);
-                ds[a] = fmaf(wy.dw[j], s[a], ds[a]);
-                ys[a] = fmaf(wy.wd[j], s[a], ys[a]);
-                sd[a] = fmaf(wy.w[j], d[a], sd[a]);
-                sz[a] = fmaf(wy.w[j], z[a], sz[a]);
+                t[j][a] = fmaf(wx.w[i], s[a], t[j][a]);
             }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            nv[a] = fmaf(wx.w[i], ss[a], nv[a]);
-            G.m[3 * a + 0] = fmaf(wx.dw[i], ss[a], G.m[3 * a + 0]);
-            B.m[3 * a + 0] = fmaf(wx.wd[i], ss[a], B.m[3 * a + 0]);
-            G.m[3 * a + 1] = fmaf(wx.w[i], ds[a], G.m[3 * a + 1]);
-            B.m[3 * a + 1] = fmaf(wx.w[i], ys[a], B.m[3 * a + 1]);
-            G.m[3 * a + 2] = fmaf(wx.w[i], sd[a], G.m[3 * a + 2]);
-            B.m[3 * a + 2] = fmaf(wx.w[i], sz[a], B.m[3 * a + 2]);
+            g0[a] = fmaf(wx.dw[i], ss[a], g0[a]);
+            b0[a] = fmaf(wx.wd[i], ss[a], b0[a]);
         }
         if (SCHED) __builtin_amdgcn_sched_barrier(0);  // keep the 27 loads of the next x-slab from being hoisted over this one
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        nv[a] = fmaf(wz.w[2], h[2][a], fmaf(wz.w[1], h[1][a], wz.w[0] * h[0][a]));
+        G.m[3 * a + 0] = g0[a];
+        B.m[3 * a + 0] = b0[a];
+        G.m[3 * a + 1] = fmaf(wy.dw[2], t[2][a], fmaf(wy.dw[1], t[1][a], wy.dw[0] * t[0][a]));
+        B.m[3 * a + 1] = fmaf(wy.wd[2], t[2][a], fmaf(wy.wd[1], t[1][a], wy.wd[0] * t[0][a]));
+        G.m[3 * a + 2] = fmaf(wz.dw[2], h[2][a], fmaf(wz.dw[1], h[1][a], wz.dw[0] * h[0][a]));
+        B.m[3 * a + 2] = fmaf(wz.wd[2], h[2][a], fmaf(wz.wd[1], h[1][a], wz.wd[0] * h[0][a]));
     }
 }
 
 // momentum_a(i,j,k) = w (mv_a + A_a . dpos) + T_a . gradw,  mass(i,j,k) = w m   with A = m C' dx (dpos in cell
-// units) and T = -dt vol inv_dx tau (gradw in cell units)
+// units) and T = -dt vol inv_dx tau (gradw in cell units).  Grouped by axis (wd = w * offset, dw = dw/dx in cell units):
+//   momentum_a = wz_k [ wy_j E_a(i) + wx_i U_a(j) ] + wx_i wy_j S_a(k)
+//   E_a(i) = wx_i mv_a + A_a0 wdx_i + T_a0 dwx_i,   U_a(j) = A_a1 wdy_j + T_a1 dwy_j,   S_a(k) = A_a2 wdz_k + T_a2 dwz_k
+// U and S do not depend on the other axes and are formed once per particle: 7 VALU instructions per node, 8 per (i, j)
+// pair, 9 per x-slab, 36 once -- 324 per particle (round 3: 486; the block kernel is VALU-issue bound).
 template <bool SCHED, class Emit>
 __device__ __forceinline__ void p2g_scatter(const Stencil& st, const float mv[3], const Mat3& A, const Mat3& T, float mass, Emit emit) {
     Weights1D wx, wy, wz;
     weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
+    float U[3][3], S[3][3];   // [component][offset]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            U[a][o] = fmaf(A.m[3 * a + 1], wy.wd[o], T.m[3 * a + 1] * wy.dw[o]);
+            S[a][o] = fmaf(A.m[3 * a + 2], wz.wd[o], T.m[3 * a + 2] * wz.dw[o]);
+        }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float e[3], tx[3];
+        float E[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            e[a] = fmaf(A.m[3 * a + 0], wx.wd[i], wx.w[i] * mv[a]);  // wx (mv + A_a0 dpx)
-            tx[a] = T.m[3 * a + 0] * wx.dw[i];
-        }
+        for (int a = 0; a < 3; ++a) E[a] = fmaf(A.m[3 * a + 0], wx.wd[i], fmaf(T.m[3 * a + 0], wx.dw[i], wx.w[i] * mv[a]));
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float wij = wx.w[i] * wy.w[j];
-            const float widj = wx.w[i] * wy.dw[j];
-            const float wijd = wx.w[i] * wy.wd[j];
-            float P[3], Q[3], R[3];
+            float P[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                P[a] = fmaf(e[a], wy.w[j], fmaf(A.m[3 * a + 1], wijd, fmaf(tx[a], wy.w[j], T.m[3 * a + 1] * widj)));
-                Q[a] = wij * A.m[3 * a + 2];
-                R[a] = wij * T.m[3 * a + 2];
-            }
+            for (int a = 0; a < 3; ++a) P[a] = fmaf(E[a], wy.w[j], wx.w[i] * U[a][j]);
             const float M = wij * mass;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float mom[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) mom[a] = fmaf(wz.w[k], P[a], fmaf(wz.wd[k], Q[a], wz.dw[k] * R[a]));
+                for (int a = 0; a < 3; ++a) mom[a] = fmaf(wz.w[k], P[a], wij * S[a][k]);
                 emit(i, j, k, mom, wz.w[k] * M);
             }
         }
@@ -1040,6 +1053,9 @@ __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int l
     // reduced to one bit each), then the tile loads that find something, RB rounds = 8 x RB loads in flight -- so a node covered
     // by three items per block costs one round trip for the masks and ceil(3 / RB) for the tiles, not two per item.
     // The order of the sum is (round, candidate) whatever RB: every instantiation returns the same bits.
+    // (Round 4 tried issuing the first round's tile loads TOGETHER with the mask loads and dropping unstored nodes afterwards --
+    // one dependent round trip fewer: 12.7 -> 15.5 us per launch at 1 M, the extra requests cost more than the trip saves;
+    // profiles/r4f_mpm_grid_speculative_tile_loads_rejected.txt.)
     for (int r0 = 0; r0 < maxc; r0 += 8) {
         unsigned long long live = ~0ull;     // bit r * 8 + c: the node is present in the tile of round r0 + r, candidate c
         if (S.sparse_tiles) {                // (uniform)
@@ -1667,7 +1683,7 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
     if (g2p && p2g && fused_mods) {
         if (h->trace) launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms);
         else if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
-        else if (h->occupancy >= 6 && !pack) launch_block<true, true, 6, 0>(h, grid, st, sp, pms);
+        else if (h->occupancy >= 6) launch_block_p<true, true, 6, 0>(h, pack, grid, st, sp, pms);
         else launch_block_p<true, true, 5, 0>(h, pack, grid, st, sp, pms);
     } else {
         if (g2p) {

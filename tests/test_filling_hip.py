@@ -122,8 +122,10 @@ def test_fill_particles_with_smoothing(hip_device):
     from pixie_amd.particle_filling import fill_particles, smooth_constrained
     n, dx = 40, 1.0 / 40
     pos, op, cov = shell_scene(n=9000, seed=4)
+    cov = cov * 4.0                                              # kernels twice as wide: the support of the shell is ~7 cells thick
     pos32, op32, cov32 = (torch.from_numpy(a.astype(np.float32)).to(hip_device) for a in (pos, op, cov))
-    dens_thr, search_thr, ppc = 2.0, 3.0, 1                      # search_threshold 3 is decode_param.py's default
+    dens_thr, search_thr, ppc = 2.0, 1.0, 1                      # search_threshold 1.0 is custom_sand_config.json's (with smooth: true):
+    #                                                              "solid" then means at least 1.5 cells inside the density's support
     out, count_d, dens_d, n_dense, n_total = fill_particles(pos32, op32[:, None], cov32, n, 300_000, dx, density_thres=dens_thr, search_thres=search_thr,
                                                             max_particles_per_cell=ppc, search_exclude_dir=5, ray_cast_dir=4, smooth=True, seed=5, return_grids=True)
     dens_h = dens_d.cpu().numpy().astype(np.float64)            # the grid as densify_grids left it (float32 atomics)
