@@ -73,6 +73,12 @@ int pixie_mpm_finalize_mu_lam(pixie_mpm* h, int with_bulk, void* stream);
 /* apply_additional_params (mpm_utils.py:591-610): box-select E, nu, density, material. */
 int pixie_mpm_apply_additional_params(pixie_mpm* h, const double point[3], const double size[3], double E,
                                       double nu, double density, int material, void* stream);
+/* The same for a LIST of boxes in one launch, with the result of applying them one after the other in list order (a particle
+ * inside several boxes keeps the LAST one's values).  material_field.py:343-363 uploads the material field as one 1 mm box
+ * per particle -- N launches of N threads in the reference; here one launch.  Device arrays: d_boxes[n_boxes][6] =
+ * (point.xyz, size.xyz) float32, d_params[n_boxes][3] = (E, nu, density) float32, d_material[n_boxes] int32. */
+int pixie_mpm_apply_additional_params_batch(pixie_mpm* h, int64_t n_boxes, const float* d_boxes, const float* d_params,
+                                            const int32_t* d_material, void* stream);
 
 /* Grid boundary conditions, applied in registration order after the grid update. */
 enum { PIXIE_BC_SURFACE = 0, PIXIE_BC_CUBOID = 1, PIXIE_BC_BBOX = 2 };

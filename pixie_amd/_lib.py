@@ -92,6 +92,7 @@ SIGNATURES = {
     "pixie_mpm_update_mass": (_I, [_VP, _VP]),
     "pixie_mpm_finalize_mu_lam": (_I, [_VP, _I, _VP]),
     "pixie_mpm_apply_additional_params": (_I, [_VP, _D3, _D3, _D, _D, _D, _I, _VP]),
+    "pixie_mpm_apply_additional_params_batch": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "pixie_mpm_add_bc": (_I, [_VP, C.POINTER(BCDesc)]),
     "pixie_mpm_add_particle_modifier": (_I, [_VP, C.POINTER(PModDesc), _VP]),
     "pixie_mpm_step": (_I, [_VP, _D, _I, _VP]),
@@ -174,9 +175,14 @@ def check(rc: int, what: str = ""):
 
 
 def current_stream_ptr():
-    """hipStream_t of torch's current stream as an integer (0 = default stream)."""
+    """hipStream_t of torch's current stream as a void pointer (value 0 / None = the default stream).  The raw getter is ~5x
+    cheaper than building a torch.cuda.Stream object, which matters for callers that ask once per substep (the deferred
+    p2g2p of the MPM shim: 1000 calls per frame)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def d3(v):

@@ -120,6 +120,7 @@ class MPM_Simulator_WARP:
         self._lost_reported = 0
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.n_particles = int(n_particles)
         self.n_grid = int(n_grid)
         self.grid_lim = float(grid_lim)
@@ -157,6 +158,14 @@ class MPM_Simulator_WARP:
     @property
     def _stream(self):
         return _lib.current_stream_ptr()
+
+    def _raw_stream(self) -> int:
+        """torch's current stream on this solver's device as an integer handle (0 = the default stream), the cheap way: the
+        deferred p2g2p() asks once per substep."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self._dev_index) or 0
+        except AttributeError:
+            return _lib.current_stream_ptr().value or 0
 
     @property
     def time(self):
@@ -300,14 +309,27 @@ class MPM_Simulator_WARP:
                 self._set_scalar(key, kwargs[key])
         if "additional_material_params" in kwargs:  # :435-463
             lib = _lib.load()
-            for params in kwargs["additional_material_params"]:
+            plist = kwargs["additional_material_params"]
+            for params in plist:
                 if isinstance(params["material"], str):
                     params["material"] = get_material_name(params["material"])
-                self.flush()
-                check(lib.pixie_mpm_apply_additional_params(self._h, d3(params["point"]), d3(params["size"]),
-                                                            float(params["E"]), float(params["nu"]),
-                                                            float(params["density"]), int(params["material"]),
-                                                            self._stream), "apply_additional_params")
+            self.flush()
+            if len(plist) > 4:
+                # material_field.py:343-363 sends one 1 mm box PER PARTICLE (N launches of N threads in the reference): one
+                # launch here, with the result of applying the boxes in list order (the last box containing a particle wins)
+                boxes = np.array([[*p["point"], *p["size"]] for p in plist], dtype=np.float32).reshape(-1, 6)
+                vals = np.array([[p["E"], p["nu"], p["density"]] for p in plist], dtype=np.float32).reshape(-1, 3)
+                mats = np.array([int(p["material"]) for p in plist], dtype=np.int32)
+                tb, tv, tm = (torch.from_numpy(a).to(self.device) for a in (boxes, vals, mats))
+                check(lib.pixie_mpm_apply_additional_params_batch(self._h, len(plist), C.c_void_p(tb.data_ptr()), C.c_void_p(tv.data_ptr()),
+                                                                  C.c_void_p(tm.data_ptr()), self._stream), "apply_additional_params_batch")
+                torch.cuda.current_stream().synchronize()      # the three staging tensors die with this frame
+            else:
+                for params in plist:
+                    check(lib.pixie_mpm_apply_additional_params(self._h, d3(params["point"]), d3(params["size"]),
+                                                                float(params["E"]), float(params["nu"]),
+                                                                float(params["density"]), int(params["material"]),
+                                                                self._stream), "apply_additional_params")
             self._update_mass()
 
     def _regrid(self, n_grid, grid_lim):
@@ -349,7 +371,7 @@ class MPM_Simulator_WARP:
         """:514-637 -- one substep.  Deferred: the substep is queued and runs, fused with its neighbours, when the
         solver is next observed or changed (module docstring); a change of dt flushes what was queued first."""
         dt = float(dt)
-        stream = self._stream.value or 0
+        stream = self._raw_stream()
         # a change of dt -- or of the CURRENT STREAM (ADVICE r3: a caller that wraps part of its loop in torch.cuda.stream(s)
         # must get its substeps on the stream they were issued under, not on whatever is current at flush time) -- ends a batch
         if self._pending and (dt != self._pending_dt or stream != self._pending_stream):
@@ -363,7 +385,7 @@ class MPM_Simulator_WARP:
     def run(self, dt, n_substeps):
         """n substeps of p2g2p in one call (fused G2P->P2G->grid launches, no host synchronisation)."""
         dt = float(dt)
-        stream = self._stream.value or 0
+        stream = self._raw_stream()
         if self._pending and (dt != self._pending_dt or stream != self._pending_stream):
             self.flush()
         self._pending_dt = dt

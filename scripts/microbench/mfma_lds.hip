@@ -2,6 +2,7 @@
 // (24 MFMAs on 8 accumulators per tap) with the B fragments (a) kept in registers, (b) re-read from LDS every tap
 // (8 x ds_read_b128), (c) re-read from LDS one tap ahead (software prefetch), at 1 or 2 workgroups per CU.
 #include <hip/hip_runtime.h>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,7 +66,36 @@ void run(const char* name, const uint4* w, float* out, int wgs, size_t lds_bytes
     printf("%-44s %7.3f ms  %7.1f TFLOP/s f16 MFMA (%.1f %% of 2500)\n", name, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0);
 }
 
-int main() {
+// `mfma_lds.exe sustain <seconds>`: the random-operand loop (B from LDS + A from global, 2 WG/CU) back to back for that long,
+// so that the board power can be sampled around it (scripts/conv_energy.py): prints launches, ms per launch, FLOP per launch.
+static int sustain(double seconds) {
+    uint4* wr; float* out;
+    CK(hipMalloc(&wr, 8192 * 16)); CK(hipMalloc(&out, 4096 * 256 * 4));
+    unsigned* h = (unsigned*)malloc(8192 * 16);
+    unsigned x = 12345u;
+    for (int i = 0; i < 8192 * 4; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((x >> 3) & 0x83ff83ffu) | 0x3c003c00u; }
+    CK(hipMemcpy(wr, h, 8192 * 16, hipMemcpyHostToDevice));
+    auto kern = k<3, 2>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int taps = 27 * 64, wgs = 2048;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 78 * 1024, 0, wr, out, taps, 1300, 1);
+    CK(hipDeviceSynchronize());
+    long launches = 0; float total_ms = 0.f;
+    while (total_ms < seconds * 1e3) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 78 * 1024, 0, wr, out, taps, 1300, 1);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms; launches += 50;
+    }
+    const double flop = (double)wgs * 4 * taps * 24 * 2.0 * 32 * 32 * 16;
+    printf("SUSTAIN launches %ld ms_per_launch %.4f flop_per_launch %.6e tflops %.1f\n", launches, total_ms / launches, flop, flop / (total_ms / launches) / 1e9);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 3 && std::string(argv[1]) == "sustain") return sustain(atof(argv[2]));
     uint4* w; float* out;
     CK(hipMalloc(&w, 8192 * 16)); CK(hipMemset(w, 0x3c, 8192 * 16)); CK(hipMalloc(&out, 4096 * 256 * 4));
     run<0, 2>("B in registers, 2 WG/CU (78 KB LDS each)", w, out, 2048, 78 * 1024);

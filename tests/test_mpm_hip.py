@@ -284,6 +284,63 @@ def test_latency_optimised_variant_matches(hip_device):
     assert rel_l2(res[1]["v"], res[0]["v"]) < 1e-4
 
 
+def test_step_graph_equals_host_launches(hip_device):
+    """pixie_mpm_step replays the steady part of a step loop as a captured HIP graph (32 substeps per launch) whenever nothing
+    the kernels compute depends on the time inside the chunk; everything else goes through the ordinary launches.  Same
+    kernels, same arguments, same order: bit-identical, with time windows opening and closing inside the rollout, a
+    moving cuboid (never captured), a reset window, re-binnings."""
+    sc = mpm_ball_scene(12000, seed=31, scenario="ball")
+    dt = sc["dt"]
+    sc["bcs"] = [dict(type="bounding_box"),
+                 dict(type="cuboid", point=[1.0, 1.0, 0.55], size=[0.3, 0.3, 0.05], velocity=[0.0, 0.0, 0.0], start_time=0.0, end_time=90.5 * dt, reset=1),
+                 dict(type="cuboid", point=[1.0, 1.3, 1.0], size=[0.1, 0.1, 0.1], velocity=[0.0, 0.2, 0.0], start_time=300.5 * dt, end_time=340.5 * dt),
+                 dict(type="particle_impulse", force=[0.0, 0.02, 0.0], num_dt=50, start_time=150.5 * dt),
+                 dict(type="enforce_particle_translation", point=[1.0, 1.0, 1.4], size=[0.2, 0.2, 0.1], velocity=[0.1, 0.0, 0.0], start_time=0.0, end_time=60.5 * dt)]
+    res = {}
+    for mode in (1, 0):
+        h = make_hip(sc)
+        h._set_scalar("step_graph", mode)
+        h.run(dt, 450)
+        h.run(dt, 70)          # a second call: the graph of the first one is still valid if nothing was re-binned
+        res[mode] = {f: get(h, f) for f in ("x", "v", "F_trial", "C")}
+        res[mode]["graphed"] = int(h._get_scalar("graph_substeps"))
+        res[mode]["time"] = h.time
+        assert h.out_of_bounds == 0
+    assert res[0]["graphed"] == 0 and res[1]["graphed"] >= 128, res[1]["graphed"]
+    assert res[0]["time"] == res[1]["time"]
+    for f in ("x", "v", "F_trial", "C"):
+        assert np.array_equal(res[0][f], res[1][f]), f
+
+
+def test_additional_material_params_batch_equals_sequential_launches(hip_device):
+    """material_field.py:343-363 uploads the field as one 1 mm box per particle through set_parameters_dict(
+    {"additional_material_params": [...]}): N sequential launches in the reference (a particle within 1 mm of a later one
+    takes the LATER one's values).  The one-launch path must leave exactly what the sequential launches leave."""
+    from pixie_amd import _lib
+    from pixie_amd._lib import check, d3
+    sc = mpm_ball_scene(3000, seed=21)
+    rng = np.random.default_rng(2)
+    x = sc["x"].copy()
+    x[1500:] = x[:1500] + rng.uniform(-6e-4, 6e-4, size=(1500, 3)).astype(np.float32)     # pairs closer than 1 mm: boxes overlap
+    sc["x"] = x
+    plist = [dict(point=x[i].tolist(), size=[0.001, 0.001, 0.001], density=float(200 + i), E=float(1e5 + 7 * i), nu=float(0.2 + 1e-5 * i),
+                  material=int(i % 7)) for i in range(3000)]
+    plist.append(dict(point=[1.0, 1.0, 1.2], size=[0.2, 0.3, 0.1], density=50.0, E=3e4, nu=0.11, material="snow"))     # a big late box
+    a, b = make_hip(sc), make_hip(sc)
+    a.set_parameters_dict({"additional_material_params": [dict(p) for p in plist]})
+    lib = _lib.load()
+    from pixie_amd.mpm_solver import get_material_name
+    for p in plist:
+        mat = get_material_name(p["material"]) if isinstance(p["material"], str) else p["material"]
+        check(lib.pixie_mpm_apply_additional_params(b._h, d3(p["point"]), d3(p["size"]), float(p["E"]), float(p["nu"]), float(p["density"]), int(mat),
+                                                    b._stream), "apply_additional_params")
+    b._update_mass()
+    for f in ("E", "nu", "density", "material", "mass"):
+        assert np.array_equal(get(a, f), get(b, f)), f
+    later = get(a, "density")[:1500] != (200 + np.arange(1500))
+    assert later.sum() > 100                      # many particles did take a later box's values
+
+
 def test_deferred_substeps_keep_the_stream_they_were_queued_on(hip_device):
     """p2g2p() only queues; the batch must be enqueued on the stream that was current when it was queued, and a
     change of the current stream ends the batch."""
