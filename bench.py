@@ -819,6 +819,12 @@ def compact_line(d, detail_path=None):
             cb = m["cpu_baseline"]
             line[f"{tag}_cpu_baseline"] = {**_pick(cb, "unit", "cores", "kind"), "value": _r(cb["value"]), "sample": cb["sample"][:110],
                                            "single_core_value": _r((cb.get("single_core") or {}).get("value"))}
+    two = (d.get("mpm_1m") or {}).get("two_scenes")
+    if two:
+        line["mpm_1m_2_scenes_particle_steps_per_s"] = _r(two["value"])
+        line["mpm_1m_2_scenes_us_per_scene_substep"] = _r(two["us_per_scene_substep"])
+        line["mpm_1m_2_scenes_frac_touched"] = _r(two["frac_touched_cells"])
+        line["mpm_1m_2_scenes_frac_dense"] = _r(two["frac_dense_grid"])
     m = d.get("mpm") or {}
     line["mpm_frac"] = line.get("mpm_frac_dense")
     if m.get("p2g2p_loop"):
@@ -884,6 +890,15 @@ def main():
             if m_large is not None:
                 m_large_alt = bench_mpm(args, rank, world, device, 1_000_000, 120, min(args.mpm_large_substeps, 500), "1m",
                                         scatter_bits=other_bits[m_large["config"]["scatter_bits"]])
+            if m_large is not None:
+                # two 1 M scenes on two streams: the latency-bound grid kernel of one scene runs under the VALU-bound block kernel
+                # of the other (a single scene cannot overlap them: each needs the other's output)
+                two = bench_mpm_multi_scene(args, device, 1_000_000, 120, min(args.mpm_large_substeps, 600), 2)
+                per_scene_us = two["us_per_substep_per_scene"] / 2.0
+                m_large["two_scenes"] = {"value": two["value"], "unit": "particle-steps/s", "scenes": 2, "us_per_scene_substep": per_scene_us, "finite": two["finite"],
+                                         "frac_dense_grid": m_large["substep_bytes_dense"] / (per_scene_us * 1e-6) / 1e9 / PEAK_HBM_GBPS,
+                                         "frac_touched_cells": m_large["substep_bytes_touched"] / (per_scene_us * 1e-6) / 1e9 / PEAK_HBM_GBPS,
+                                         "config": two["config"]}
             m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
             six = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 6)
             m_multi["six_scenes"] = {k: six[k] for k in ("value", "unit", "scenes", "us_per_substep_per_scene", "finite")}

@@ -1474,15 +1474,6 @@ struct pixie_mpm {
     bool dirty_grid = false;                 // gin holds an un-consumed P2G (phase API)
     // profiling
     bool profile = false;
-    // ---- the steady part of a step loop replayed as a HIP graph (pixie_mpm_step) ----
-    int step_graph = 1;                      // set_scalar "step_graph": 0 = launch every kernel from the host
-    unsigned long long epoch = 0;            // bumped by every call that changes what the step kernels read (parameters, fields, BCs ...)
-    hipStream_t cap_stream = nullptr;        // capture happens here (torch's current stream is usually the legacy stream, which cannot capture)
-    hipGraphExec_t sg_exec = nullptr;        // kStepGraphSubsteps x (grid kernel, fused block kernel)
-    unsigned long long sg_epoch = 0, sg_sorts = 0;
-    float sg_dt = 0.0f;
-    unsigned long long sg_pmod_mask = 0, sg_bc_state = 0;
-    long long graph_substeps = 0;            // substeps run through the graph so far (get_scalar "graph_substeps")
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_particle, ev_grid;
 };
 
@@ -1915,8 +1906,6 @@ int pixie_mpm_create(pixie_mpm** out, int n_particles, int n_grid, double grid_l
 }
 
 int pixie_mpm_destroy(pixie_mpm* h) {
-    if (h && h->sg_exec) { (void)hipGraphExecDestroy(h->sg_exec); h->sg_exec = nullptr; }
-    if (h && h->cap_stream) { (void)hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
     if (!h) return 0;
     for (void* p : h->allocs) (void)hipFree(p);
     for (void* p : h->grid_allocs) (void)hipFree(p);
@@ -1930,7 +1919,6 @@ int pixie_mpm_destroy(pixie_mpm* h) {
 
 int pixie_mpm_regrid(pixie_mpm* h, int n_grid, double grid_lim, void* stream) {
     PX_REQUIRE(h && n_grid >= 4 && grid_lim > 0, "pixie_mpm_regrid: bad arguments");
-    ++h->epoch;     // whatever the captured step graph was built for may have changed
     PX_REQUIRE(!h->dirty_grid, "pixie_mpm_regrid: a phase-API P2G is pending");
     PX_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));   // nothing may still be reading the old grid
     if (alloc_grid(h, n_grid, grid_lim)) return 1;
@@ -2028,7 +2016,6 @@ int pixie_mpm_fill_field(pixie_mpm* h, const char* name, double value, void* str
 
 int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     PX_REQUIRE(h && key, "pixie_mpm_set_scalar: null argument");
-    ++h->epoch;     // whatever the captured step graph was built for may have changed
     const std::string k(key);
     if (k == "rpic_damping") h->rpic = (float)value;
     else if (k == "grid_v_damping_scale") h->damping = (float)value;
@@ -2051,7 +2038,6 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "sparse_tiles") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "sparse_tiles must be -1 (auto), 0 or 1"); h->sparse = (int)value; h->needs_sort = true; }
     else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
     else if (k == "trace") h->trace = (int)value;
-    else if (k == "step_graph") h->step_graph = value != 0 ? 1 : 0;
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
@@ -2075,8 +2061,6 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "mass_contrast") *value = h->mass_contrast;
     else if (k == "n_active_blocks") *value = h->n_active;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
-    else if (k == "graph_substeps") *value = (double)h->graph_substeps;
-    else if (k == "step_graph") *value = h->step_graph;
     else if (k == "lost_particles_seen") *value = (double)h->lost_seen;   // as of the last re-binning; does not synchronise
     else if (k == "dropped_particles") {  // slow-path particles that had left every active block; synchronises the device
         unsigned long long v = 0;
@@ -2130,7 +2114,6 @@ int pixie_mpm_apply_additional_params_batch(pixie_mpm* h, int64_t n_boxes, const
 
 int pixie_mpm_add_bc(pixie_mpm* h, const pixie_bc_desc* bc) {
     PX_REQUIRE(h && bc, "null argument");
-    ++h->epoch;     // whatever the captured step graph was built for may have changed
     PX_REQUIRE(bc->type >= 0 && bc->type <= 2, "add_bc: unknown type %d", bc->type);
     h->bcs.push_back(*bc);
     h->bcs_dev.push_back(to_dev(*bc));
@@ -2139,7 +2122,6 @@ int pixie_mpm_add_bc(pixie_mpm* h, const pixie_bc_desc* bc) {
 
 int pixie_mpm_add_particle_modifier(pixie_mpm* h, const pixie_pmod_desc* pm, void* stream) {
     PX_REQUIRE(h && pm, "null argument");
-    ++h->epoch;     // whatever the captured step graph was built for may have changed
     PX_REQUIRE(pm->type >= 0 && pm->type <= 2, "add_particle_modifier: unknown type %d", pm->type);
     PModDev m{};
     m.type = pm->type;
@@ -2161,89 +2143,11 @@ int pixie_mpm_add_particle_modifier(pixie_mpm* h, const pixie_pmod_desc* pm, voi
     return 0;
 }
 
-// ---- the steady part of a step loop as ONE graph launch per kStepGraphSubsteps substeps ----------------------------------------------
-// A substep is two dependent launches; on this part an empty producer/consumer pair of the same geometry costs 5.7 us from the
-// host and 3.6 us inside a captured graph (scripts/microbench/launch_chain.hip, profiles/r4g_launch_chain_floor.txt) -- 2 us of
-// an 18 us substep at 100 k particles.  The kernels take the time by value, so a captured chunk can only be REPLAYED at another
-// time when nothing they compute depends on it: every boundary condition and particle modifier must be in the same state
-// (inside / outside its window, inside / outside a cuboid's reset window) at every substep of the chunk as when it was
-// captured, no cuboid may be moving, and no re-binning may fall into the chunk.  That is checked on the host with the
-// kernels' own float comparisons; whatever fails runs through the ordinary launches.  Same kernels, same arguments, same order:
-// the results are bit-identical (tests/test_mpm_hip.py::test_step_graph_equals_host_launches).
-constexpr int kStepGraphSubsteps = 32;
-
-// state of every time-dependent switch the kernels evaluate, at grid time t and block time t + dt (bit per BC / modifier)
-static bool step_state(const pixie_mpm* h, double t, double dt, unsigned long long* pm_mask, unsigned long long* bc_state) {
-    const float tg = (float)t, tb = (float)(t + dt), dtf = (float)dt;
-    unsigned long long bits = 0;
-    if (h->bcs_dev.size() > 30 || h->pmods.size() > 60) return false;
-    for (size_t k = 0; k < h->bcs_dev.size(); ++k) {
-        const BCDev& b = h->bcs_dev[k];
-        const bool win = tg >= b.start && tg < b.end;
-        const bool rst = b.type == PIXIE_BC_CUBOID && !win && b.reset == 1 && tg < b.end + 15.0f * dtf;
-        if (b.type == PIXIE_BC_CUBOID && win && (b.velocity[0] != 0.0f || b.velocity[1] != 0.0f || b.velocity[2] != 0.0f)) return false;   // moving
-        bits |= (unsigned long long)win << (2 * k) | (unsigned long long)rst << (2 * k + 1);
-    }
-    *bc_state = bits;
-    const std::vector<PModDev> act = active_pmods(h, tb, pm_mask);
-    return act.size() <= (size_t)kMaxPModFused;
-}
-
-// 0 = the next kStepGraphSubsteps substeps went through the graph; 1 = not eligible (nothing was launched); -1 = error
-static int try_step_graph(pixie_mpm* h, double dt, int remaining, hipStream_t st) {
-    const int G = kStepGraphSubsteps;
-    if (!h->step_graph || h->profile || h->trace || remaining <= G) return 1;      // (the last substep of a call is G2P-only: stays outside)
-    if (!h->pending_p2g || h->needs_sort || h->n_items == 0 || h->bcs_dev.size() > (size_t)kMaxBCPerLaunch) return 1;
-    if (h->resort_interval > 0 && h->steps_since_sort + G - 1 >= h->resort_interval) return 1;
-    unsigned long long pm0 = 0, bc0 = 0;
-    double t = h->time;
-    if (!step_state(h, t, dt, &pm0, &bc0)) return 1;
-    if ((pm0 != 0) != h->pmods_were_active) return 1;
-    for (int k = 1; k < G; ++k) {
-        t = t + dt;
-        unsigned long long pm = 0, bc = 0;
-        if (!step_state(h, t, dt, &pm, &bc) || pm != pm0 || bc != bc0) return 1;
-    }
-    const bool fresh = h->sg_exec && h->sg_epoch == h->epoch && h->sg_sorts == (unsigned long long)h->n_sorts && h->sg_dt == (float)dt &&
-                       h->sg_pmod_mask == pm0 && h->sg_bc_state == bc0;
-    if (!fresh) {
-        if (h->sg_exec) { (void)hipGraphExecDestroy(h->sg_exec); h->sg_exec = nullptr; }
-        if (!h->cap_stream) PX_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-        const BCSet set = make_bcset(h, 0);
-        PModSet pms{};
-        const std::vector<PModDev> act = active_pmods(h, (float)(h->time + dt));
-        pms.n = (int)act.size();
-        for (int k = 0; k < pms.n; ++k) pms.pm[k] = act[k];
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); h->step_graph = 0; return 1; }
-        double tc = h->time;
-        for (int k = 0; k < G; ++k) {
-            launch_grid_blocks(h, h->cap_stream, make_params(h, dt, tc), set, 0, std::max(h->n_active, 1));
-            tc = tc + dt;
-            launch_fused_block(h, h->cap_stream, make_params(h, dt, tc), pms);
-        }
-        hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
-        if (e == hipSuccess) e = hipGraphInstantiate(&h->sg_exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { (void)hipGetLastError(); h->sg_exec = nullptr; h->step_graph = 0; return 1; }    // this runtime cannot: host launches from now on
-        h->sg_epoch = h->epoch; h->sg_sorts = (unsigned long long)h->n_sorts; h->sg_dt = (float)dt; h->sg_pmod_mask = pm0; h->sg_bc_state = bc0;
-    }
-    PX_CHECK_HIP(hipGraphLaunch(h->sg_exec, st));
-    // the host-side bookkeeping of G ordinary substeps
-    StepParams last_grid{};
-    for (int k = 0; k < G; ++k) {
-        last_grid = make_params(h, dt, h->time);
-        h->time = h->time + dt;
-    }
-    h->steps_since_sort += G;
-    h->pending_p2g = true;
-    h->gout_sparse = true;
-    h->last_grid_sp = last_grid;
-    h->last_grid_bcs.assign(h->bcs_dev.begin(), h->bcs_dev.end());
-    h->graph_substeps += G;
-    return 0;
-}
-
+// (Round 4 captured the steady part of this loop -- 32 substeps of grid kernel + fused block kernel -- as a HIP graph, replayed
+// whenever nothing the kernels compute depended on the time inside the chunk.  Bit-identical, and no faster: 18.00 vs 18.10 us
+// per substep at 100 k particles, 63.8 vs 63.2 at 1 M; with several scenes sharing the GPU it was slower (two 1 M scenes: 128.8
+// vs 109.8 us per pair of substeps).  The host already runs far ahead of the device, so what a substep pays at its two kernel
+// boundaries is the device's own 3.6 us, graph or not.  profiles/r4h_mpm_step_graph_rejected.txt)
 int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream) {
     PX_REQUIRE(h && n_substeps >= 0, "pixie_mpm_step: bad arguments");
     if (n_substeps == 0) return 0;
@@ -2252,11 +2156,6 @@ int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream) {
     // substep 0: modifiers + stress + P2G at time t0
     if (launch_particle(h, false, true, make_params(h, dt, h->time), st)) return 1;
     for (int i = 0; i < n_substeps; ++i) {
-        {
-            const int rc = try_step_graph(h, dt, n_substeps - i, st);
-            if (rc < 0) return 1;
-            if (rc == 0) { i += kStepGraphSubsteps - 1; continue; }
-        }
         if (launch_grid(h, make_params(h, dt, h->time), dt, st)) return 1;
         h->time = h->time + dt;  // mpm_solver_warp.py:637
         const bool last = (i == n_substeps - 1);

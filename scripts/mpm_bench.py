@@ -30,7 +30,7 @@ def main():
         s._set_scalar("occupancy", int(os.environ["PIXIE_MPM_OCC"]))
     if os.environ.get("PIXIE_MPM_ITEM_CAP"):
         s._set_scalar("item_cap", int(os.environ["PIXIE_MPM_ITEM_CAP"]))
-    for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb"), ("PIXIE_MPM_STEP_GRAPH", "step_graph")):
+    for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb")):
         if os.environ.get(env):
             s._set_scalar(key, int(os.environ[env]))
     s.run(sc["dt"], int(os.environ.get("PIXIE_MPM_WARM", "64")))
@@ -51,7 +51,7 @@ def main():
           f"bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
-          f"active blocks {int(s._get_scalar('n_active_blocks'))} rebins {int(s._get_scalar('n_rebins'))} (timed region: {rebins_timed}) graphed {int(s._get_scalar('graph_substeps'))} slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "
+          f"active blocks {int(s._get_scalar('n_active_blocks'))} rebins {int(s._get_scalar('n_rebins'))} (timed region: {rebins_timed}) slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "
           f"finite {bool(torch.isfinite(s.get_field('x')).all())}", flush=True)
 
 

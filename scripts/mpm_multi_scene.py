@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""N independent MPM scenes on N HIP streams of one GPU (bench.py's multi-scene leg on its own), with the step-graph switch."""
+"""N independent MPM scenes on N HIP streams of one GPU (bench.py's multi-scene leg on its own)."""
 import os
 import sys
 import types
@@ -11,16 +11,7 @@ import bench  # noqa: E402
 
 n, ng, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 scenes = [int(v) for v in sys.argv[4].split(",")]
-mode = os.environ.get("PIXIE_MPM_STEP_GRAPH")
-if mode is not None:
-    orig = bench._mpm_solver
-
-    def patched(sc, scatter_bits=None):
-        s = orig(sc, scatter_bits)
-        s._set_scalar("step_graph", int(mode))
-        return s
-    bench._mpm_solver = patched
 dev = torch.device("cuda", 0)
 for k in scenes:
     r = bench.bench_mpm_multi_scene(types.SimpleNamespace(), dev, n, ng, steps, k)
-    print(f"step_graph={mode} {k} scenes x {n} particles (n_grid {ng}): {r['value']:.4e} particle-steps/s, {r['us_per_substep_per_scene']:.2f} us per substep of the batch, finite {r['finite']}", flush=True)
+    print(f"{k} scenes x {n} particles (n_grid {ng}): {r['value']:.4e} particle-steps/s, {r['us_per_substep_per_scene']:.2f} us per substep of the batch, finite {r['finite']}", flush=True)

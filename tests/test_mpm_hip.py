@@ -284,34 +284,6 @@ def test_latency_optimised_variant_matches(hip_device):
     assert rel_l2(res[1]["v"], res[0]["v"]) < 1e-4
 
 
-def test_step_graph_equals_host_launches(hip_device):
-    """pixie_mpm_step replays the steady part of a step loop as a captured HIP graph (32 substeps per launch) whenever nothing
-    the kernels compute depends on the time inside the chunk; everything else goes through the ordinary launches.  Same
-    kernels, same arguments, same order: bit-identical, with time windows opening and closing inside the rollout, a
-    moving cuboid (never captured), a reset window, re-binnings."""
-    sc = mpm_ball_scene(12000, seed=31, scenario="ball")
-    dt = sc["dt"]
-    sc["bcs"] = [dict(type="bounding_box"),
-                 dict(type="cuboid", point=[1.0, 1.0, 0.55], size=[0.3, 0.3, 0.05], velocity=[0.0, 0.0, 0.0], start_time=0.0, end_time=90.5 * dt, reset=1),
-                 dict(type="cuboid", point=[1.0, 1.3, 1.0], size=[0.1, 0.1, 0.1], velocity=[0.0, 0.2, 0.0], start_time=300.5 * dt, end_time=340.5 * dt),
-                 dict(type="particle_impulse", force=[0.0, 0.02, 0.0], num_dt=50, start_time=150.5 * dt),
-                 dict(type="enforce_particle_translation", point=[1.0, 1.0, 1.4], size=[0.2, 0.2, 0.1], velocity=[0.1, 0.0, 0.0], start_time=0.0, end_time=60.5 * dt)]
-    res = {}
-    for mode in (1, 0):
-        h = make_hip(sc)
-        h._set_scalar("step_graph", mode)
-        h.run(dt, 450)
-        h.run(dt, 70)          # a second call: the graph of the first one is still valid if nothing was re-binned
-        res[mode] = {f: get(h, f) for f in ("x", "v", "F_trial", "C")}
-        res[mode]["graphed"] = int(h._get_scalar("graph_substeps"))
-        res[mode]["time"] = h.time
-        assert h.out_of_bounds == 0
-    assert res[0]["graphed"] == 0 and res[1]["graphed"] >= 128, res[1]["graphed"]
-    assert res[0]["time"] == res[1]["time"]
-    for f in ("x", "v", "F_trial", "C"):
-        assert np.array_equal(res[0][f], res[1][f]), f
-
-
 def test_additional_material_params_batch_equals_sequential_launches(hip_device):
     """material_field.py:343-363 uploads the field as one 1 mm box per particle through set_parameters_dict(
     {"additional_material_params": [...]}): N sequential launches in the reference (a particle within 1 mm of a later one
