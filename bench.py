@@ -414,7 +414,7 @@ def load_traffic():
         return {}
 
 
-def _mpm_solver(sc, scatter_bits=None):
+def _mpm_solver(sc, scatter_bits=None, wide=None):
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
@@ -422,6 +422,8 @@ def _mpm_solver(sc, scatter_bits=None):
     apply_scene(s, sc)
     if scatter_bits:
         s._set_scalar("scatter_bits", scatter_bits)
+    if wide is not None:
+        s._set_scalar("wide", wide)
     return s
 
 
@@ -495,7 +497,10 @@ def bench_mpm_multi_scene(args, device, particles, n_grid, substeps, n_scenes):
     loop is a foreign call that releases the GIL) share the GPU.  Reports aggregate particle-steps/s for this GPU."""
     import threading
     scenes = [mpm_ball_scene(particles, seed=10 + i, n_grid=n_grid) for i in range(n_scenes)]
-    solvers = [_mpm_solver(sc) for sc in scenes]
+    # (a scene alone picks the latency-optimised block-kernel variant when it cannot fill the chip -- 130 VGPRs, three workgroups
+    # per CU; scenes that SHARE the chip want the five-per-CU variant back: PIXIE_MPM_MULTI_WIDE=-1 keeps the per-scene rule)
+    wide = int(os.environ.get("PIXIE_MPM_MULTI_WIDE", "0"))
+    solvers = [_mpm_solver(sc, wide=wide) for sc in scenes]
     streams = [torch.cuda.Stream(device) for _ in range(n_scenes)]
 
     def work(i, n):
