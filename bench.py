@@ -497,10 +497,7 @@ def bench_mpm_multi_scene(args, device, particles, n_grid, substeps, n_scenes):
     loop is a foreign call that releases the GIL) share the GPU.  Reports aggregate particle-steps/s for this GPU."""
     import threading
     scenes = [mpm_ball_scene(particles, seed=10 + i, n_grid=n_grid) for i in range(n_scenes)]
-    # (a scene alone picks the latency-optimised block-kernel variant when it cannot fill the chip -- 130 VGPRs, three workgroups
-    # per CU; scenes that SHARE the chip want the five-per-CU variant back: PIXIE_MPM_MULTI_WIDE=-1 keeps the per-scene rule)
-    wide = int(os.environ.get("PIXIE_MPM_MULTI_WIDE", "0"))
-    solvers = [_mpm_solver(sc, wide=wide) for sc in scenes]
+    solvers = [_mpm_solver(sc) for sc in scenes]    # (forcing the five-waves-per-SIMD block kernel changes nothing here: profiles/r4k_mpm_multi_scene_variant.txt)
     streams = [torch.cuda.Stream(device) for _ in range(n_scenes)]
 
     def work(i, n):

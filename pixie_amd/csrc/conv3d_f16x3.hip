@@ -64,7 +64,6 @@ struct Conv16Args {
     unsigned mHX, mHYX;
     float* stats; unsigned* out_amax;   // epilogue statistics (see the epilogue), or null
     float* partial; int chunks_per_slice;   // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps) and writes partial[z]
-    int nw;                  // waves per workgroup the tiling was made for (4; 8 in the one-workgroup-per-CU experiment)
     int epi_lds;             // the launch reserved enough LDS for the transposing epilogue (4 x 32 x (32 NB + 4) + 256 MB floats)
     // Folded 1x1x1 skip convolution (MyResBlock.skip_connection, diffusion_network.py:691,705): after the main chunks the
     // accumulators are rescaled (an exact power of two) and sk_cin more channels of the RAW tensors sk_in0 | sk_in1 are
@@ -102,11 +101,11 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned
 // The LDS tile holds the 16 channels of a chunk as fp32 planes [channel][voxel] (the same 64 bytes per voxel as the four
 // fp16 planes), a lane's B operand is one conflict-free ds_read_b32, its A operand one coalesced 4-byte load from the
 // [tap][c_in][c_out] weight array (L2-resident: 442 KB for the 64 -> 64 layer), fetched one tap ahead.
-template <int KS, int MB, int NB, bool EX = false, int NW = 4>
+template <int KS, int MB, int NB, bool EX = false>
 __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     extern __shared__ uint4 smem16[];
     constexpr int PAD = (KS == 3) ? 1 : 0;
-    constexpr int NT = 64 * NW;
+    constexpr int NW = 4, NT = 64 * NW;     // (an 8-wave, one-workgroup-per-CU tile was measured in round 4: 1.350 vs 1.323 ms, profiles/r4k_conv_eight_wave_tile_rejected.txt)
     const int bufsz = 4 * A.CS;            // one buffer: hi[2][CS], lo[2][CS]
 
     const int tid = threadIdx.x;
@@ -588,12 +587,6 @@ template <int KS, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Conv16Args A) {
     conv3d_f16x3_body<KS, MB, NB>(A);
 }
-// EXPERIMENT (round 4, VERDICT r3 #5c): the same body with EIGHT waves and one workgroup per CU -- a 64 c_out x 1024-voxel tile
-// (halo 1.99 staged voxels per output voxel instead of 2.39), no second workgroup to overlap with.  PIXIE_CONV_NW8=1.
-template <int KS, int MB, int NB>
-__global__ __launch_bounds__(512, 1) void conv3d_f16x3_kernel_nw8(Conv16Args A) {
-    conv3d_f16x3_body<KS, MB, NB, false, 8>(A);
-}
 // conv_precision = "f32": the exact-fp32 variant of the same body (v_mfma_f32_32x32x2_f32)
 template <int KS, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv3d_exact_kernel(Conv16Args A) {
@@ -728,13 +721,9 @@ static void conv16_tiling(const pixie_conv_desc* d, Conv16Args& a, int& MB_out, 
         if (n_wg(MB, NB) < 512 && MB > 1) MB = 1;
     }
     if (slices_out) *slices_out = slices;
-    static const bool nw8_env = getenv("PIXIE_CONV_NW8") != nullptr;     // experiment switch, read once
-    a.nw = 4;
-    if (nw8_env && d->d_w16 && d->ksize == 3 && MB == 2 && NB == 4 && slices == 1 && a.stride == 1 && n_wg(MB, NB) >= 1024) a.nw = 8;
-
-    const int tile_vox = 32 * a.nw * NB;
+    const int tile_vox = 128 * NB;
     a.TX = pow2_le16(a.OW, 32);
-    a.TY = pow2_le16(a.OH, std::max(1, std::min(a.nw == 8 ? 8 : 4, tile_vox / a.TX)));
+    a.TY = pow2_le16(a.OH, std::max(1, std::min(4, tile_vox / a.TX)));
     a.TZ = std::max(1, std::min(a.OD, tile_vox / (a.TX * a.TY)));
     a.lTX = ilog2_16(a.TX); a.lTY = ilog2_16(a.TY);
     a.tiles_x = (a.OW + a.TX - 1) / a.TX; a.tiles_y = (a.OH + a.TY - 1) / a.TY; a.tiles_z = (a.OD + a.TZ - 1) / a.TZ;
@@ -789,8 +778,8 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     size_t lds = (size_t)4 * a.CS * sizeof(uint4);
     PX_REQUIRE(lds <= 160 * 1024, "f16x3 conv: tile needs %zu B of LDS", lds);
     {   // room for the transposing epilogue, as long as two workgroups still fit on a CU
-        const size_t epi = ((size_t)a.nw * 32 * (NB * 32 + 4) + (size_t)a.nw * MB * 32 * 2) * sizeof(float);
-        if (slices == 1 && epi <= (a.nw == 8 ? 160 : 80) * 1024) { a.epi_lds = 1; if (lds < epi) lds = epi; }
+        const size_t epi = ((size_t)4 * 32 * (NB * 32 + 4) + (size_t)4 * MB * 32 * 2) * sizeof(float);
+        if (slices == 1 && epi <= 80 * 1024) { a.epi_lds = 1; if (lds < epi) lds = epi; }
     }
     const dim3 grid((unsigned)a.n_tiles, (unsigned)((a.coutp + MB * 32 - 1) / (MB * 32)), (unsigned)slices);
     if (slices > 1) {
@@ -804,13 +793,6 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
         const long osp = (long)a.OD * a.OH * a.OW, n_elems = (long)a.cout * osp;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, a.partial, slices, n_elems, osp,
                            a.bias, a.residual, a.out);
-        PX_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
-    if (a.nw == 8) {
-        auto kern = conv3d_f16x3_kernel_nw8<3, 2, 4>;
-        PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
         PX_CHECK_HIP(hipGetLastError());
         return 0;
     }
