@@ -103,8 +103,9 @@ def test_phase_by_phase_parity(hip_device):
 
 
 def _assert_rollout_parity(h, o32, o64, sc, tag):
-    """x and F_trial within 1e-4 of the float64 oracle outright; displacement, v and C within max(1e-4, 4 x the float32
-    oracle's own distance from the float64 oracle)."""
+    """Positions are judged by the DISPLACEMENT x - x0 (the signal): within max(1e-4, 4 x the float32 oracle's own distance
+    from the float64 oracle), like v and C.  F_trial within 1e-4 of the float64 oracle outright.  (The rel-L2 of the O(1)
+    coordinate itself is kept only as a sanity line: in the quiet scenes 1e-4 there is ~100x the displacement signal.)"""
     assert abs(h.time - o64.time) < 1e-12
     x_h, F_h, v_h, C_h = get(h, "x"), get(h, "F_trial").reshape(-1, 3, 3), get(h, "v"), get(h, "C").reshape(-1, 3, 3)
     assert np.isfinite(x_h).all()
