@@ -4,10 +4,15 @@ Only tests/ may import this module, as the checker for pixie_amd/particle_fillin
 Restates third_party/PhysGaussian/particle_filling/filling.py: compute_density :13-23, densify_grids :26-92,
 fill_dense_grids :95-121 (which cells, how many points -- the points themselves are ti.random()), collision_search :124-149,
 collision_times :152-183, internal_filling :186-244, compute_particle_volume :257-266, get_attr_from_closest :383-403.
-PARITY UNPINNED: Taichi is not installed here and the reference holds no vectors for these kernels; the restatement is
-float64 and is anchored by closed-form and brute-force cases in tests/test_filling_oracle.py (a single isotropic Gaussian's
-density; one rotated anisotropic Gaussian re-computed cell by cell from the definition; a hollow shell whose interior must
-fill; a shell open on the excluded side; a torus, whose filled set must be the tube interior of the implicit equation).
+PINNED to the reference's own code (round 4): Taichi is not installed here, but filling.py is Python source -- it is imported
+UNMODIFIED on tests/golden/ti_shim (a NumPy interpreter of the Taichi subset it uses) and its fill_particles /
+get_particle_volume / init_filled_particles are run as written on five scenes (tests/golden/make_filling_ref_golden.py ->
+tests/golden/filling_ref_golden.npz).  This restatement reproduces the reference's density grids to 4e-16, its count grids
+after each of the three kernels, the filled cells, the volumes and the nearest-Gaussian attributes exactly
+(tests/test_filling_ref_golden.py, which also re-runs the reference live where /root/reference exists).  Not pinnable, because
+the reference itself leaves them undetermined: the order of the new particles and their ti.random() offsets.  The closed-form
+and brute-force anchors of tests/test_filling_oracle.py stay as a second, independent check.  The smoothing step at the end
+of this file (PyMCubes, absent) is the one part that remains unpinned; see its docstring.
 """
 from __future__ import annotations
 
