@@ -1,16 +1,15 @@
 """Second, INDEPENDENT CPU restatement of the reference's MLS-MPM substep -- TEST INFRASTRUCTURE ONLY.
 
-Only tests/ and bench.py's cpu_baseline leg may import this module, and only as the checker / the timed CPU
-baseline.  pixie_amd/ never does.
+Only tests/ may import this module, and only as the checker.  pixie_amd/ never does.
 
-Why it exists.  The MPM half of the hot path is "parity unpinned": the reference ships no vectors for the solver and
-NVIDIA Warp cannot run here, so oracle/mpm_oracle.c (a scalar, line-by-line C restatement) has nothing upstream to be
-checked against.  This file is a second restatement written directly from the reference source in a different form
-(array programming on torch CPU tensors, one batched expression per reference statement, LAPACK SVD instead of a
-hand-written Jacobi) and deliberately shares no code with mpm_oracle.c.  tests/test_mpm_vectorised.py requires the
-two to agree in float64 on every material model, every boundary condition and every particle modifier: two
-independent readings of the same source agreeing is the only anchor available.  It is also the multi-core CPU baseline
-of bench.py (torch's intra-op thread pool; `cores` = torch.get_num_threads()).
+Why it exists.  Until round 4 nothing upstream could check oracle/mpm_oracle.c (the reference ships no vectors for the
+solver and NVIDIA Warp cannot run here), so this file -- a second restatement written directly from the reference source in
+a different form (array programming on torch CPU tensors, one batched expression per reference statement, LAPACK SVD
+instead of a hand-written Jacobi), deliberately sharing no code with mpm_oracle.c -- was the anchor: tests/test_mpm_vectorised.py
+requires the two to agree in float64 on every material model, every boundary condition and every particle modifier.  Since
+round 4 the C oracle is PINNED to the reference's own solver code (tests/golden/wp_shim runs mpm_solver_warp.py unmodified;
+tests/test_mpm_ref_golden.py); this file stays as an independent cross-check.  It used to be a multi-core CPU baseline
+of bench.py (now: the C oracle under OpenMP).
 
 Restated from (paths relative to /root/reference/third_party/PhysGaussian/mpm_solver_warp):
   mpm_utils.py:10-17    kirchoff_stress_FCR            mpm_utils.py:89-135   von_mises_return_mapping

@@ -1,8 +1,8 @@
 """CPU suite for the MPM half.
 
-The reference ships no golden vectors for its solver and Warp cannot run here (PARITY UNPINNED, see
-oracle/mpm_oracle.c), so the oracle is anchored on analytic known-answer tests,
-and the device arithmetic of pixie_amd/csrc/mpm_math.h is compared against the oracle on the host.
+Analytic known-answer tests of the MPM oracle and the device arithmetic of
+pixie_amd/csrc/mpm_math.h compared against the oracle on the host.  (The oracle's pin to the reference's own solver code --
+mpm_solver_warp.py run unmodified on tests/golden/wp_shim -- is tests/test_mpm_ref_golden.py.)
 """
 import numpy as np
 import pytest

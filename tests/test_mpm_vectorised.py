@@ -1,10 +1,11 @@
 """Two independent CPU restatements of the reference's MPM substep must agree (float64).
 
-The MPM oracle is "parity unpinned" (no upstream vectors, Warp cannot run here).  oracle/mpm_oracle.c restates the
+Independent cross-check beside the pin of tests/test_mpm_ref_golden.py (the reference's own solver code run on a Warp
+interpreter).  oracle/mpm_oracle.c restates the
 reference kernels line by line in scalar C; oracle/mpm_vectorised.py restates them again, directly from the reference
 source, as batched torch expressions with a LAPACK SVD.  They share no code.  Agreement of the two on every material
-model (ids 0, 1, 2, 3, 5, 6), every grid boundary condition and every particle modifier is the anchor that stands in
-for golden vectors; what is left unanchored is a misreading of the reference made identically, twice, in two forms.
+model (ids 0, 1, 2, 3, 5, 6), every grid boundary condition and every particle modifier was the anchor until round 4
+and remains a second line of defence.
 """
 import numpy as np
 import pytest
