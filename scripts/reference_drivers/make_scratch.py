@@ -15,10 +15,13 @@ CUT with `ast` (their files cannot be imported whole: hydra / omegaconf / wandb 
     ref_map_pred.py      unscale_prediction, get_mat_id, map_pred_to_ply (pixie/voxel/map_pred_to_coords.py:41-75, 122-283)
     ref_gs_main.py       load_point_cloud (gs_simulation.py:108-202) and the statements of gs_simulation.py's __main__ block
                          that set up and drive the solver (:483-502, :531, :558-561, the frame loop :573-634 with the
-                         camera / rasteriser / image statements removed), wrapped into `simulate(...)`.
+                         camera / rasteriser / image statements removed), wrapped into `simulate(...)`; and the particle
+                         pre-pass of the same block (:413-482: rotation, sim-area crop, transform2origin, shift2center111,
+                         fill_particles, get_particle_volume, init_filled_particles), wrapped into `prepass(...)`.
 Each cut function's source text is the reference's, unmodified; the only edits are the ones INTEGRATION.md section 1 documents
 (the imports of SegmentationUNet / RegressionUNet / MPM_Simulator_WARP) -- made in the header this script writes, not in
-the function bodies -- and `frame_hook(...)`, a call appended to the frame loop so the runner can observe every frame.
+the function bodies (`from particle_filling.filling import *` becomes `from pixie_amd.particle_filling import *` the same way)
+-- and `frame_hook(...)`, a call appended to the frame loop so the runner can observe every frame.
 """
 import ast
 import os
@@ -87,12 +90,30 @@ def main_body_cut(path):
     return "\n".join(body), "\n".join(out)
 
 
+def prepass_cut(path):
+    """gs_simulation.py:413-482 of the main block: from `rotation_matrices = generate_rotation_matrices(` to the
+    `if filling_params and filling_params.get("visualize", False): ... else: ...` statement, every statement verbatim."""
+    src = open(path).read()
+    lines = src.splitlines()
+    tree = ast.parse(src)
+    main_if = next(n for n in tree.body if isinstance(n, ast.If) and "__name__" in ast.unparse(n.test))
+    body = main_if.body
+    first = next(i for i, st in enumerate(body) if (ast.get_source_segment(src, st) or "").startswith("rotation_matrices = generate_rotation_matrices("))
+    last = next(i for i, st in enumerate(body) if isinstance(st, ast.If) and ast.unparse(st.test).startswith("filling_params and filling_params.get('visualize'"))
+    assert 0 < first < last
+    out = []
+    for st in body[first:last + 1]:
+        out.append(f"    # gs_simulation.py:{st.lineno}-{st.end_lineno} (verbatim)\n" + "\n".join(lines[st.lineno - 1:st.end_lineno]))
+    return "\n".join(out)
+
+
 def main():
     shutil.rmtree(OUT, ignore_errors=True)
     os.makedirs(os.path.join(OUT, "utils"))
     for src, dst in ((f"{PG}/material_field.py", "material_field.py"), (f"{PG}/utils/decode_param.py", "utils/decode_param.py"),
                      (f"{PG}/utils/transformation_utils.py", "utils/transformation_utils.py"),
                      (f"{PG}/config/objaverse/custom_tree_config.json", "custom_tree_config.json"),
+                     (f"{PG}/config/objaverse/custom_sand_config.json", "custom_sand_config.json"),
                      (f"{PG}/config/objaverse/custom_sport_balls_config.json", "custom_sport_balls_config.json")):
         shutil.copyfile(src, os.path.join(OUT, dst))
     open(os.path.join(OUT, "utils", "__init__.py"), "w").close()
@@ -122,6 +143,7 @@ def main():
         '"""Cut from third_party/PhysGaussian/gs_simulation.py by scripts/reference_drivers/make_scratch.py -- see there."""',
         "import numpy as np\nimport torch\nfrom plyfile import PlyData, PlyElement\n\n"
         "from mpm_solver_warp.mpm_solver_warp import MPM_Simulator_WARP      # resolves to pixie_amd.mpm_solver (INTEGRATION.md section 1)\n"
+        "from pixie_amd.particle_filling import *      # INTEGRATION.md section 1 (was: from particle_filling.filling import *)\n"
         "from material_field import apply_material_field_to_simulation, transform_to_original_coordinates\n"
         "from utils.decode_param import *\nfrom utils.transformation_utils import *",
         cut(f"{PG}/gs_simulation.py", ["load_point_cloud"]),
@@ -135,6 +157,10 @@ def main():
         "    mpm_init_cov = torch.zeros((mpm_init_pos.shape[0], 6), device=device)\n"
         "    mpm_init_cov[:gs_num] = init_cov\n"
         + setup + "\n" + loop + "\n    return mpm_solver",
+        "def prepass(preprocessing_params, material_params, init_pos, init_cov, init_opacity, init_shs):\n"
+        "    \"\"\"The particle pre-pass of gs_simulation.py's main block, in order.  Inputs = the variables that block holds at line 412\n"
+        "    (the opacity-filtered Gaussians of the splat model, which is out of scope); returns its locals.\"\"\"\n"
+        + prepass_cut(f"{PG}/gs_simulation.py") + "\n    return dict(locals())",
     ])
     open(os.path.join(OUT, "ref_gs_main.py"), "w").write(gs + "\n")
     print("wrote", sorted(os.listdir(OUT)))

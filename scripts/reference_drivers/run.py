@@ -16,6 +16,10 @@ container): the only edits are the import swaps INTEGRATION.md section 1 documen
                      same class surface: per-frame positions / covariances handed to the rasteriser must agree.
                      Also decides the `live_exports` default: does the driver ever read an exported tensor it held
                      across p2g2p calls without re-exporting?
+  D. particle pre-pass  gs_simulation.py:413-482 verbatim (rotation, transform2origin, shift2center111, fill_particles,
+                     get_particle_volume, init_filled_particles) with the reference's custom_sand_config.json -- the config
+                     that sets `"smooth": true` -- on pixie_amd.particle_filling; the result is checked against the chain
+                     of oracle/filling_oracle.py (pinned to the reference's filling.py) on the same Gaussians.
 Writes gpurun_out/reference_drivers.log (copied to profiles/ by the session script).  Exit code 0 = every check passed.
 """
 import argparse
@@ -300,18 +304,93 @@ def part_c(root, ply_path, n_particles, frames):
     assert ok
 
 
+# ============================================================================================ D. the particle pre-pass
+def part_d(n_gaussians):
+    import ref_gs_main as G
+    from oracle import filling_oracle as fo
+    from utils.decode_param import decode_param_json
+    material_params, bc_params, time_params, preprocessing_params, camera_params = decode_param_json(os.path.join(SCRATCH, "custom_sand_config.json"))
+    fp = preprocessing_params["particle_filling"]
+    assert fp["smooth"] is True and fp["visualize"] is True and material_params["material"] == "sand"
+    # synthetic "Gaussians" in the splat model's own frame: a closed shell (the reference loads them from a trained 3DGS model)
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(n_gaussians, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos = (d * np.array([0.8, 0.7, 0.75]) + np.array([0.3, -0.2, 0.1])).astype(np.float32)
+    sig = rng.uniform(0.020, 0.030, size=(n_gaussians, 3)) * np.array([1.0, 0.85, 1.15])          # x 1/1.6 after transform2origin: 1-1.8 filling cells
+    Q = np.linalg.qr(rng.normal(size=(n_gaussians, 3, 3)))[0]
+    S = Q @ (sig[:, :, None] ** 2 * np.eye(3)) @ Q.transpose(0, 2, 1)
+    cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+    opa = rng.uniform(0.5, 1.0, size=(n_gaussians, 1)).astype(np.float32)
+    shs = rng.normal(size=(n_gaussians, 16, 3)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    t0 = time.perf_counter()
+    L = G.prepass(preprocessing_params, material_params, t(pos), t(cov), t(opa), t(shs))
+    torch.cuda.synchronize()
+    gs_num0 = n_gaussians
+    n_all = L["mpm_init_pos"].shape[0]
+    say(f"D. gs_simulation.py:413-482 on pixie_amd.particle_filling with custom_sand_config.json (filling grid {fp['n_grid']}^3 in the box {fp['boundary'][:2]}, "
+        f"density_threshold {fp['density_threshold']}, search_threshold {fp['search_threshold']}, exclude {fp['search_exclude_direction']}, smooth=True, visualize=True): "
+        f"{gs_num0} Gaussians -> {n_all} particles in {time.perf_counter() - t0:.1f} s")
+    assert L["gs_num"] == n_all and L["mpm_init_vol"].shape == (n_all,) and L["mpm_init_cov"].shape == (n_all, 6)
+    assert L["shs_render"].shape == (n_all, 16, 3) and L["opacity_render"].shape == (n_all, 1)
+    # --- the same chain on the pinned oracle, from the arrays the reference code handed to fill_particles
+    tp, tc = L["transformed_pos"].cpu().numpy(), L["init_cov"].cpu().numpy()
+    bnd, n = fp["boundary"], fp["n_grid"]
+    dx = np.float64(np.float32(max(bnd[1] - bnd[0], bnd[3] - bnd[2], bnd[5] - bnd[4]) / n))
+    lo = np.array([bnd[0], bnd[2], bnd[4]], np.float32)
+    assert ((tp > lo) & (tp < np.array([bnd[1], bnd[3], bnd[5]], np.float32))).all()
+    count0, dens = fo.densify((tp - lo).astype(np.float64), opa, tc, n, dx)
+    dense, per = fo.dense_cells(count0, dens, fp["density_threshold"], fp["max_partciels_per_cell"])
+    count1 = np.where(dense, fp["max_partciels_per_cell"], count0)
+    sm = fo.smooth_constrained(dens.astype(np.float32).astype(np.float64), max_iters=500).astype(np.float32)
+    inside = fo.internal_cells(count1, sm, fp["search_threshold"], fp["search_exclude_direction"], fp["ray_cast_direction"])
+    want = int(per.sum() + fp["max_partciels_per_cell"] * inside.sum())
+    new = L["mpm_init_pos"][gs_num0:].cpu().numpy()
+    cell = np.floor((new - lo).astype(np.float64) / dx).astype(int)
+    hist = np.zeros((n,) * 3, int)
+    np.add.at(hist, tuple(np.clip(cell, 0, n - 1).T), 1)
+    expect = np.where(inside, fp["max_partciels_per_cell"], 0) + per
+    differing = int((hist != expect).sum())
+    # the smoothed field is compared against a threshold after 500 Jacobi sweeps in float64 on the device vs scipy: a handful of
+    # cells within ~1e-6 of the threshold may fall either side (and flip the cells on their rays)
+    say(f"   new particles: {len(new)} (oracle chain on the same Gaussians: {want}; dense cells {int(dense.sum())}, internal cells {int(inside.sum())}); "
+        f"cells whose particle count differs from the oracle chain: {differing}")
+    assert abs(len(new) - want) <= max(3, want // 1000) and differing <= max(6, want // 500)
+    assert torch.equal(L["mpm_init_pos"][:gs_num0], L["transformed_pos"])
+    # volumes: sand -> uniform (gs_simulation.py:470)
+    vol = L["mpm_init_vol"].cpu().numpy()
+    ref_vol = fo.particle_volume(L["mpm_init_pos"].cpu().numpy().astype(np.float64), material_params["n_grid"],
+                                 np.float64(np.float32(material_params["grid_lim"] / material_params["n_grid"])))
+    say(f"   get_particle_volume(unifrom=True): {vol[0]:.6e} everywhere (oracle mean {ref_vol.mean():.6e})")
+    assert np.ptp(vol) == 0 and abs(vol[0] - ref_vol.mean()) < 1e-5 * ref_vol.mean()
+    # attributes of the filled particles: the nearest original Gaussian's (a sample, brute force on the host)
+    pick = rng.choice(len(new), size=min(400, len(new)), replace=False)
+    idx = fo.nearest(tp, new[pick])
+    assert np.array_equal(L["mpm_init_cov"][gs_num0:].cpu().numpy()[pick], tc[idx])
+    assert np.array_equal(L["opacity_render"][gs_num0:, 0].cpu().numpy()[pick], opa[idx, 0])
+    assert np.array_equal(L["shs_render"][gs_num0:].cpu().numpy()[pick], shs[idx])
+    say(f"   init_filled_particles: covariance / opacity / SH rows of {len(pick)} sampled new particles equal their nearest Gaussian's (brute force)")
+    return L
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=64)        # map_pred_to_ply asserts a 64^3 mask (map_pred_to_coords.py:182)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--particles", type=int, default=20000)
     ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=20000)
+    ap.add_argument("--only", default="abcd")
     a = ap.parse_args()
     assert torch.cuda.is_available(), "needs the GPU box"
     root = tempfile.mkdtemp(prefix="pixie_ref_drivers_")
-    cfg, out_dir, obj_ids = part_a(root, a.grid, a.channels)
-    ply = part_b(cfg, out_dir, obj_ids[0], stable_field=True)
-    part_c(root, ply, a.particles, a.frames)
+    if "a" in a.only or "b" in a.only or "c" in a.only:
+        cfg, out_dir, obj_ids = part_a(root, a.grid, a.channels)
+        ply = part_b(cfg, out_dir, obj_ids[0], stable_field=True)
+    if "c" in a.only:
+        part_c(root, ply, a.particles, a.frames)
+    if "d" in a.only:
+        part_d(a.gaussians)
     say("ALL CHECKS PASSED")
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     open(os.path.join(REPO, "gpurun_out", "reference_drivers.log"), "w").write("\n".join(LOG) + "\n")
