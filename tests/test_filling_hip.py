@@ -160,8 +160,8 @@ _REF_SCENES = sorted(_json.loads(str(np.load(_REF_FIXTURE)["meta"])))
 def test_product_matches_the_reference_code_fixture(hip_device, name):
     """tests/golden/filling_ref_golden.npz holds what the reference's own filling.py computed (run unmodified on the Taichi
     interpreter of tests/golden/ti_shim): the product must fill the same cells with the same number of particles, reproduce
-    the density grid to float32 accuracy (bar: 1e-5 rel-L2; the reference's own float32 run sits 1e-7..3e-7 from its float64
-    self), and give the same volumes and nearest-Gaussian attributes.  Every threshold of the fixture is >= 2e-4 away from
+    the density grid to float32 accuracy (bar: 1e-6 rel-L2; measured 1.1e-7..1.4e-7, the reference's own float32 run sits
+    1e-7..3e-7 from its float64 self), and give the same volumes and nearest-Gaussian attributes.  Every threshold of the fixture is >= 2e-4 away from
     every cell's density, so no integer result hinges on a rounding."""
     from pixie_amd.particle_filling import fill_particles, get_particle_volume, init_filled_particles
     z = np.load(_REF_FIXTURE)
@@ -172,7 +172,7 @@ def test_product_matches_the_reference_code_fixture(hip_device, name):
     out, count_d, dens_d, n_dense, n_total = fill_particles(pos, op[:, None], cov, m["grid_n"], 200_000, m["grid_dx"], seed=1, return_grids=True, **kw)
     err = rel_l2(dens_d.cpu().numpy(), z[name + "/density"])
     print(f"[{name}] density vs the reference's float64 run: {err:.2e} (the reference's float32 run: {m['density_drift_f32']:.2e})")
-    assert err < 1e-5
+    assert err < 1e-6
     assert np.array_equal(count_d.cpu().numpy(), z[name + "/count_after_internal_filling"])
     assert n_dense == m["n_dense"] and n_total == m["n_total"] and out.shape[0] == len(pos) + n_total
     assert torch.equal(out[:len(pos)], pos)
