@@ -33,6 +33,9 @@ def main():
     for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb")):
         if os.environ.get(env):
             s._set_scalar(key, int(os.environ[env]))
+    if os.environ.get("PIXIE_MPM_V0"):     # a scene in motion: random particle velocities of this rms per component (strains of a few %)
+        g = torch.Generator().manual_seed(1)
+        s.import_particle_v_from_torch(float(os.environ["PIXIE_MPM_V0"]) * torch.randn((n, 3), generator=g))
     s.run(sc["dt"], int(os.environ.get("PIXIE_MPM_WARM", "64")))
     torch.cuda.synchronize()
     rebins0 = int(s._get_scalar("n_rebins"))
@@ -48,7 +51,7 @@ def main():
     s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
     print(f"n={n} ng={ng} resort={resort} {scenario} occ={os.environ.get('PIXIE_MPM_OCC', '5')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', '256')} "
-          f"bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
+          f"bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} v0={os.environ.get('PIXIE_MPM_V0', '0')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
           f"active blocks {int(s._get_scalar('n_active_blocks'))} rebins {int(s._get_scalar('n_rebins'))} (timed region: {rebins_timed}) slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "

@@ -17,6 +17,13 @@ of its particles with det F < 0 and is stored under both conventions (`inverted`
 show what depends on the convention and that the oracle follows Warp's.
 
 Run in the build container (needs /root/reference):   python tests/golden/make_mpm_ref_golden.py      (~2 min)
+
+`--long` writes tests/golden/mpm_ref_long_golden.npz instead: two ROLLOUTS of 150 substeps by the same reference code (the tree
+scenario of PhysGaussian/config/objaverse/custom_tree_config.json on a ball with per-particle E / nu / density, and a sand
+column falling onto a sticky floor with the flags of custom_sand_config.json), checkpoints at 50 / 100 / 150 substeps, 20^3
+grid, 600 / 500 particles -- how the restatements track the reference's own code over a rollout rather than a few substeps;
+a metal column likewise; and `knife_edge_floor`, three substeps of a scene whose collider plane coincides with a node plane, stored
+in BOTH evaluations because they differ (see long_scenes).  (~35 min: every kernel thread is interpreted.)
 """
 import json
 import os
@@ -160,6 +167,59 @@ def scenes():
     return out
 
 
+def long_scenes():
+    out = {}
+    n_grid = 20
+    # the tree scenario (BASELINE configs[2]; gs_simulation.py with custom_tree_config.json): zero gravity, grid damping 0.9999,
+    # one impulse on a box of particles for one substep, a sticky ground slab, bounding box; per-particle material fields as
+    # apply_material_field_to_simulation leaves them
+    rng = np.random.default_rng(21)
+    n = 600
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x = (1.0 + 0.42 * d * rng.uniform(0, 1, (n, 1)) ** (1 / 3)).astype(np.float32)
+    vol = np.full(n, 4 / 3 * np.pi * 0.42 ** 3 / n, np.float32)
+    arr = dict(x0=x, vol=vol, cov=np.tile(np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32), (n, 1)),
+               E=(10 ** rng.uniform(5.0, 6.3, n)).astype(np.float32), nu=rng.uniform(0.2, 0.4, n).astype(np.float32),
+               density=rng.uniform(200, 2000, n).astype(np.float32),
+               v0=(0.6 * rng.normal(size=(n, 3))).astype(np.float32))          # (the config's impulse alone moves the ball by 1e-4 of a cell)
+    out["tree_rollout"] = (dict(params=dict(n_grid=n_grid, grid_lim=GRID_LIM, material="jelly", E=2e5, nu=0.3, density=1000.0, g=[0.0, 0.0, 0.0],
+                                            grid_v_damping_scale=0.9999, rpic_damping=0.0),
+                                calls=[["add_bounding_box", {}],
+                                       ["set_velocity_on_cuboid", dict(point=[1.0, 1.0, 0.62], size=[1.0, 1.0, 0.06], velocity=[0.0, 0.0, 0.0],
+                                                                       start_time=0.0, end_time=1e3, reset=0)],
+                                       ["add_impulse_on_particles", dict(force=[-0.48, 0.0, 0.0], dt=DT, point=[1.0, 1.0, 1.25], size=[0.5, 0.5, 0.2],
+                                                                         num_dt=1, start_time=0.0)]]), arr)
+    # a column falling onto a sticky floor under gravity: sand with the flags of custom_sand_config.json (friction_angle 30, sticky
+    # surface collider, bounding box), and metal (von Mises with hardening).  The floor plane lies BETWEEN two node planes (6.3 dx).
+    def column(seed, z0):
+        rng = np.random.default_rng(seed)
+        n = 500
+        x = np.stack([rng.uniform(0.8, 1.2, n), rng.uniform(0.8, 1.2, n), rng.uniform(z0, 1.3, n)], 1).astype(np.float32)
+        return dict(x0=x, vol=np.full(n, 0.4 * 0.4 * (1.3 - z0) / n, np.float32), cov=np.tile(np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32), (n, 1)),
+                    v0=(np.array([0.0, 0.0, -1.5]) + 0.3 * rng.normal(size=(n, 3))).astype(np.float32))
+
+    def floor(z):
+        return [["add_bounding_box", {}],
+                ["add_surface_collider", dict(point=[1.0, 1.0, z], normal=[0.0, 0.0, 1.0], surface="sticky", friction=0.0, start_time=0.0, end_time=1e3)]]
+    out["sand_rollout"] = (dict(params=dict(n_grid=n_grid, grid_lim=GRID_LIM, material="sand", E=5e5, nu=0.3, density=2000.0, g=[0.0, 0.0, -9.8],
+                                            friction_angle=30.0), calls=floor(0.63)), column(22, 0.66))
+    out["metal_rollout"] = (dict(params=dict(n_grid=n_grid, grid_lim=GRID_LIM, material="metal", E=2e6, nu=0.3, density=2700.0, g=[0.0, 0.0, -9.8],
+                                             yield_stress=2e3, hardening=1, xi=0.2), calls=floor(0.63)), column(23, 0.66))
+    # The knife edge: a collider plane that COINCIDES with a node plane (plane z = 0.6, dx = 0.1f).  Whether those nodes are "below"
+    # it (mpm_solver_warp.py:821-840: dot(x_node - point, normal) < 0) is decided by the last bit of float(k) * dx - point:
+    # evaluated in float32 with every operation rounded, 6 * 0.1f rounds to exactly 0.6f and the node plane is NOT in the collider;
+    # evaluated exactly on the same float32 data (float64 here; a fused multiply-add in a float32 build -- what nvcc and hipcc
+    # contract `float(k) * dx - p` into by default) 6 * 0.1f - 0.6f = -1.5e-8 and it IS.  The two evaluations of the reference's
+    # own source differ by 16 % in v after ONE substep; which one a float32 build gives is the compiler's contraction choice, not
+    # the source's.  This scene stores both (`k*_f32/...`) so the tests can say which side an implementation is on.
+    # (custom_sand_config.json's own floor, z = 0.48 with dx = 0.01f, is NOT such a case: 48 * 0.01f equals 0.48f exactly.)
+    out["knife_edge_floor"] = (dict(params=dict(n_grid=n_grid, grid_lim=GRID_LIM, material="sand", E=5e5, nu=0.3, density=2000.0, g=[0.0, 0.0, -9.8],
+                                                friction_angle=30.0), calls=floor(0.6), store_f32=True, checkpoints=[1, 3]), column(24, 0.62))
+    for sc, _ in out.values():
+        sc.update(n_grid=n_grid, grid_lim=GRID_LIM, dt=DT, checkpoints=sc.get("checkpoints", [50, 100, 150]))
+    return out
+
+
 def rollout(scene, arrays, precision, svd="warp"):
     wp.set_precision(precision)
     wp.set_svd_convention(svd)
@@ -188,7 +248,8 @@ def rel(a, b):
 def main():
     t0 = time.time()
     store, meta = {}, {}
-    for name, (scene, arrays) in scenes().items():
+    long_run = "--long" in sys.argv
+    for name, (scene, arrays) in (long_scenes() if long_run else scenes()).items():
         variants = [(name, "warp")] + ([(name + "_lapack", "lapack")] if name == "inverted" else [])
         for vname, svd in variants:
             s64, e64, order = rollout(scene, arrays, "f64", svd)
@@ -199,6 +260,8 @@ def main():
             for cp in scene["checkpoints"]:
                 for f in STATE_FIELDS:
                     store[f"{vname}/k{cp}/{f}"] = s64[cp][f]
+                    if scene.get("store_f32"):
+                        store[f"{vname}/k{cp}_f32/{f}"] = s32[cp][f]
                 store[f"{vname}/drift/k{cp}"] = np.array([rel(s32[cp][f], s64[cp][f]) for f in STATE_FIELDS])
                 store[f"{vname}/drift_dx/k{cp}"] = np.float64(rel(s32[cp]["x"] - arrays["x0"], s64[cp]["x"] - arrays["x0"]))
             for k, v in e64.items():
@@ -206,7 +269,7 @@ def main():
             worst = max(store[f"{vname}/drift/k{scene['checkpoints'][-1]}"])
             print(f"{vname:18s} launches/substep {len(order):3d}  f32-vs-f64 worst field drift {worst:.2e}   [{time.time() - t0:.0f} s]", flush=True)
     store["meta"] = np.array(json.dumps(meta))
-    path = os.path.join(HERE, "mpm_ref_golden.npz")
+    path = os.path.join(HERE, "mpm_ref_long_golden.npz" if long_run else "mpm_ref_golden.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

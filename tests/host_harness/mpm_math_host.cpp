@@ -24,6 +24,14 @@ void hh_stress(int n, const int* material, const float* Ft, float* mu, float* la
         for (int i = 0; i < 9; ++i) { Fout[9 * p + i] = F.m[i]; tau[9 * p + i] = T.m[i]; }
     }
 }
+void hh_polar(int n, const float* A, float* Rout, int* ok) {
+    for (int p = 0; p < n; ++p) {
+        Mat3 F, R;
+        for (int i = 0; i < 9; ++i) F.m[i] = A[9 * p + i];
+        ok[p] = polar_rotation(F, R) ? 1 : 0;
+        for (int i = 0; i < 9; ++i) Rout[9 * p + i] = R.m[i];
+    }
+}
 void hh_stencil(int n, const float* x, float inv_dx, int* base, float* w, float* dw) {
     for (int p = 0; p < n; ++p) {
         Stencil s = make_stencil(x[3 * p], x[3 * p + 1], x[3 * p + 2], inv_dx);

@@ -169,6 +169,41 @@ def test_device_stress_matches_oracle(material, scale, ys):
     assert np.allclose(mu, o.field("mu"), rtol=1e-6) and np.allclose(lam, o.field("lam"), rtol=1e-6)
 
 
+def test_polar_iteration_converges_with_and_without_scaling():
+    """polar_rotation (mpm_math.h, host build): the Frobenius scaling is applied only to iterates far from a rotation
+    (|sum s_i^2 - 3| > 0.5 or |det - 1| > 0.5).  Sweep singular values over both regions, the corners of the unscaled one
+    included, and nearly rigid inputs (the one-step exit: |cof F - F|_F^2 < 2e-8): the iteration must settle within its six steps and give the polar factor U V^T to float32 accuracy; det <= 0
+    must be refused (the caller then takes the SVD route)."""
+    lib = _harness.load()
+    rng = np.random.default_rng(5)
+    def rot(n):
+        q = np.linalg.qr(rng.normal(size=(n, 3, 3)))[0]
+        return q * np.sign(np.linalg.det(q))[:, None, None]
+    cases = []
+    for lo, hi, n in ((0.99995, 1.00005, 1500), (0.9997, 1.0003, 1500), (0.985, 1.015, 2000), (0.9, 1.1, 2000), (0.7, 1.4, 3000), (0.28, 1.6, 3000), (0.15, 3.0, 2000)):
+        cases.append(rng.uniform(lo, hi, size=(n, 3)))
+    corners = np.array([[1.32, 1.32, 0.29], [1.58, 0.9, 0.45], [1.45, 0.62, 0.97], [1.35, 0.74, 1.0], [1.0, 1.0, 1.0], [1.2, 1.2, 1.2], [0.8, 0.8, 0.8]])
+    sv = np.concatenate(cases + [corners])
+    n = len(sv)
+    U, V = rot(n), rot(n)
+    F = np.ascontiguousarray((U * sv[:, None, :]) @ V.transpose(0, 2, 1), dtype=np.float32)
+    R = np.zeros_like(F); ok = np.zeros(n, np.int32)
+    lib.hh_polar(n, F.ctypes.data, R.ctypes.data, ok.ctypes.data)
+    want = U @ V.transpose(0, 2, 1)
+    unscaled = (np.abs((sv ** 2).sum(1) - 3) <= 0.5) & (np.abs(sv.prod(1) - 1) <= 0.5)
+    assert 6000 < unscaled.sum() < n - 1000                         # both regions are populated
+    assert ok[unscaled].all()                                        # the plain iteration settles wherever it is chosen
+    assert ok.mean() > 0.99
+    err = np.abs(R - want).reshape(n, -1).max(1)
+    print("polar: settled", ok.mean(), "max |R - U V^T|", err[ok == 1].max(), "unscaled region", err[unscaled].max())
+    assert err[ok == 1].max() < 5e-6 and err[unscaled].max() < 2e-6
+    # reflected input: refused
+    Fm = np.ascontiguousarray(F[:50]).copy(); Fm[:, :, 0] *= -1
+    okm, Rm = np.ones(50, np.int32), np.zeros_like(Fm)
+    lib.hh_polar(50, Fm.ctypes.data, Rm.ctypes.data, okm.ctypes.data)
+    assert not okm.any()
+
+
 def test_device_stencil_matches_oracle():
     lib = _harness.load()
     rng = np.random.default_rng(3)

@@ -17,6 +17,11 @@ from tests._mpm_ref_driver import OracleAdapter, STATE_FIELDS, load_fixture, run
 FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "mpm_ref_golden.npz")
 SCENES = load_fixture(FIXTURE)
 TOL = 1e-10     # float64 oracle vs float64 evaluation of the reference's kernels (measured: <= 5e-13)
+LONG_FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "mpm_ref_long_golden.npz")
+LONG = load_fixture(LONG_FIXTURE)     # two 150-substep rollouts by the same reference code (make_mpm_ref_golden.py --long)
+TOL_LONG = 1e-6   # the same comparison after 150 substeps of contact and plastic flow: the yield decisions and the degenerate SVDs of
+#                   nearly undeformed particles amplify the last bit -- measured: tree 1.9e-7, sand 8.8e-8, metal 2.4e-7 (grid_v_out), two to
+#                   three orders below the distance of the reference's own float32 evaluation from its float64 one (1e-4 .. 1e-3)
 
 
 def rel(a, b):
@@ -58,6 +63,63 @@ def test_oracle_equals_reference_code(name):
         assert (ref[f"k{scene['checkpoints'][-1]}/mu"] == 0).any(), "no particle lost its stiffness"
     if name == "mixed_materials":
         assert set(np.unique(mat)) == {0, 1, 2, 3, 5, 6}
+
+
+ROLLOUTS = [n for n in sorted(LONG) if not LONG[n][0].get("store_f32")]
+
+
+def test_knife_edge_collider_plane():
+    """A collider plane on a node plane: `float(k) * dx - point < 0` is decided by the last bit (see make_mpm_ref_golden.py,
+    long_scenes).  The reference's source evaluated with every float32 operation rounded and evaluated exactly disagree about
+    a whole plane of nodes; the float64 oracle must follow the exact evaluation, the float32 oracle (gcc, no contraction) the
+    rounded one -- each to its usual accuracy -- and the two fixtures must really be far apart."""
+    scene, arrays, ref = LONG["knife_edge_floor"]
+    _, s64 = oracle_rollout(scene, arrays, "f64")
+    _, s32 = oracle_rollout(scene, arrays, "f32")
+    for cp in scene["checkpoints"]:
+        for f in ("x", "v", "C", "F", "stress"):
+            # (1e-8, not TOL: the column starts from F = I, where the singular values are degenerate and the two SVDs -- LAPACK in
+            # the fixture, Jacobi in the oracle -- pick different bases; the reconstruction amplifies 1e-16 by the inverse gap)
+            assert rel(s64[cp][f], ref[f"k{cp}/{f}"]) < 1e-8, (cp, f)
+        assert rel(s32[cp]["v"], ref[f"k{cp}_f32/v"]) < 1e-5 and rel(s32[cp]["F"], ref[f"k{cp}_f32/F"]) < 1e-5
+        assert rel(ref[f"k{cp}_f32/v"], ref[f"k{cp}/v"]) > 0.05
+
+
+@pytest.mark.parametrize("name", ROLLOUTS)
+def test_oracle_tracks_the_reference_code_over_a_rollout(name):
+    """150 substeps (checkpoints at 50 / 100 / 150): the tree scenario of custom_tree_config.json on a moving ball, and a sand
+    and a metal column hitting a sticky floor (custom_sand_config.json's flags; von Mises with hardening).  The oracle must still be ON the reference's numbers,
+    and its float32 build must have drifted from them by about as much as the reference's own float32 run has."""
+    scene, arrays, ref = LONG[name]
+    ad, snaps = oracle_rollout(scene, arrays)
+    worst = {}
+    for cp in scene["checkpoints"]:
+        for f in STATE_FIELDS:
+            worst[f] = max(worst.get(f, 0.0), rel(snaps[cp][f], ref[f"k{cp}/{f}"]))
+    for f in ("grid_m", "grid_v_in", "grid_v_out"):
+        worst[f] = rel(ad.read(f), ref[f])
+    cov, R = ad.exports()
+    worst["cov"], worst["R"] = rel(cov, ref["cov_out"]), rel(R, ref["R_out"])
+    print(name, {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < TOL_LONG, worst
+    assert abs(ad.time - float(ref["time"])) < 1e-12
+    last = scene["checkpoints"][-1]
+    moved = np.linalg.norm(ref[f"k{last}/x"] - arrays["x0"], axis=1)
+    assert np.median(moved) > 5e-4                                   # a rollout, not a perturbation: > 0.5 % of a cell for most particles
+    if name == "metal_rollout":
+        assert (ref[f"k{last}/yield_stress"] > 2.0e3 * 1.5).sum() > 20  # hardened
+    if name == "sand_rollout":                                       # the column reached the floor and flowed plastically
+        F = ref[f"k{last}/F"].reshape(len(moved), 9)
+        assert (ref[f"k{last}/x"][:, 2] < 0.69).sum() > 20 and np.abs(F - np.eye(3).reshape(9)).max() > 1e-3
+    _, s32 = oracle_rollout(scene, arrays, "f32")
+    ours = np.array([rel(s32[last][f], ref[f"k{last}/{f}"]) for f in STATE_FIELDS])
+    print(name, "float32 oracle vs reference f64:", {f: f"{a:.1e}" for f, a in zip(STATE_FIELDS, ours)},
+          "| the reference's own float32 evaluation:", {f: f"{b:.1e}" for f, b in zip(STATE_FIELDS, ref[f"drift/k{last}"])})
+    for f, a, b in zip(STATE_FIELDS, ours, ref[f"drift/k{last}"]):
+        # The fixture's float32 run takes its SVDs from LAPACK (sgesdd, accurate to an ulp); the oracle's float32 build runs the
+        # Jacobi SVD of the restatement in float32, as Warp's svd3 does on the GPU -- noisier, and a plastic rollout feeds that
+        # noise back through the yield surface every substep (metal: v 1.4e-4 against 8.8e-6, C 4.4e-4 against 4.1e-5).  Within 16x, or inside 3e-4.
+        assert a < 16 * max(b, 1e-7) or a < 3e-4, (name, f, a, b)
 
 
 def test_float32_oracle_drifts_like_the_reference_code_in_float32():

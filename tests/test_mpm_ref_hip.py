@@ -24,6 +24,7 @@ from tests._mpm_ref_driver import ProductAdapter, STATE_FIELDS, load_fixture, ru
 pytestmark = pytest.mark.gpu
 
 SCENES = load_fixture(os.path.join(os.path.dirname(__file__), "golden", "mpm_ref_golden.npz"))
+LONG = load_fixture(os.path.join(os.path.dirname(__file__), "golden", "mpm_ref_long_golden.npz"))      # 150-substep rollouts
 
 
 def rel(a, b):
@@ -31,10 +32,38 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
+def test_knife_edge_collider_plane(hip_device):
+    """A collider plane that coincides with a node plane (tests/golden/make_mpm_ref_golden.py, long_scenes): the reference's
+    source gives two answers, 16 % apart in v after one substep -- every float32 operation rounded (the plane's nodes are outside
+    the collider) or `float(k) * dx - point` evaluated exactly, as a fused multiply-add does (they are inside).  hipcc contracts
+    the expression (as nvcc does for the reference's kernels by default), so the product must sit ON the exact evaluation, to its
+    usual accuracy, and far from the other one."""
+    scene, arrays, ref = LONG["knife_edge_floor"]
+    ad = ProductAdapter(scene, arrays)
+    snaps = {}
+    run(ad, scene, arrays, lambda cp, st: snaps.__setitem__(cp, st))
+    for cp in scene["checkpoints"]:
+        exact, rounded = rel(snaps[cp]["v"], ref[f"k{cp}/v"]), rel(snaps[cp]["v"], ref[f"k{cp}_f32/v"])
+        print(f"knife edge k{cp}: v vs the exact evaluation {exact:.2e}, vs the all-rounded float32 evaluation {rounded:.2e}")
+        assert exact < 1e-5 and rounded > 0.05
+
+
+@pytest.mark.parametrize("bits", (64, 32))
+@pytest.mark.parametrize("name", [n for n in sorted(LONG) if not LONG[n][0].get("store_f32")])
+def test_product_tracks_the_reference_code_over_a_rollout(hip_device, name, bits):
+    """The same comparison after 50 / 100 / 150 substeps of the reference's own code (tree scenario on a moving ball; sand and
+    metal columns onto a sticky floor): the same bars, scaled by the reference's own float32 drift at each checkpoint."""
+    _compare(LONG[name], name, bits)
+
+
 @pytest.mark.parametrize("bits", (64, 32))
 @pytest.mark.parametrize("name", [n for n in SCENES if not n.endswith("_lapack")])
 def test_product_equals_reference_code(hip_device, name, bits):
-    scene, arrays, ref = SCENES[name]
+    _compare(SCENES[name], name, bits)
+
+
+def _compare(entry, name, bits):
+    scene, arrays, ref = entry
     ad = ProductAdapter(scene, arrays, scatter_bits=bits)
     snaps = {}
     run(ad, scene, arrays, lambda cp, st: snaps.__setitem__(cp, st))
