@@ -192,8 +192,8 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
     sig[2] = u2[0] * B(0, 2) + u2[1] * B(1, 2) + u2[2] * B(2, 2);
 }
 
-// Rotation factor R of the polar decomposition F = R S by the Newton iteration
-// R <- (g R + R^-T / g) / 2 (g = 1, or the Frobenius scale in the first two steps of an iterate far from a rotation): a third of the instructions and of
+// Rotation factor R of the polar decomposition F = R S by the scaled Newton iteration
+// R <- (g R + R^-T / g) / 2 (two Frobenius-scaled steps, then plain ones): a third of the instructions and of
 // the dependency chain of svd3.  For det F > 0 it equals U V^T of the reference's wp.svd3 to fp32 roundoff, which is
 // all kirchoff_stress_FCR (mpm_utils.py:10-17) needs.  Returns false when the iteration has not settled (extreme
 // conditioning) or det F <= 0 (inverted element, where U V^T of the proper-rotation SVD is NOT the polar factor);
@@ -204,8 +204,7 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
 // A step entered with max (s_i - 1) = e leaves e^2 / 2: an iterate with |R|_F^2 - 3 < 4e-4 (e < 2e-4) needs exactly one more
 // step (2e-8, below fp32 roundoff), and that step is the lane's last.  A lane stops at ITS OWN last step (the iterate is
 // frozen afterwards), so its result does not depend on which other particles share its wave; the wave leaves the loop once
-// every lane has stopped -- after 1 of the 6 steps where every lane is within 1e-4 of a rotation, after 2 for strains below
-// ~1.5 %, after 3 for the strains of a stable simulation.
+// every lane has stopped -- after 2 of the 6 steps for strains below ~1.5 %, after 3 for the strains of a stable simulation.
 PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
     R = F;
     float det = 1.0f;
@@ -227,55 +226,27 @@ PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
         const float d = R.m[0] * cof.m[0] + R.m[1] * cof.m[1] + R.m[2] * cof.m[2];
         if (it == 0) det = d;
         const float inv_d = px_rcp(d);
-        // `last`: the entering iterate is within 2e-4 of a rotation, so this step is the lane's last.
-        //   it >= 1: |R|_F^2 - 3 bounds the distance (see above; NaN never passes).
-        //   it == 0: the singular values may straddle 1 and cancel in |F|_F^2 - 3, but cof F = U diag(s_j s_k) V^T, so
-        //            |cof F - F|_F^2 = sum_i (s_j s_k - s_i)^2 = sum_i (S - 2 e_i)^2 to first order (s_i = 1 + e_i, S = sum e):
-        //            max |e_i| <= 1.37 |cof F - F|_F.  Below 2e-8 (|.|_F < 1.4e-4) a nearly rigid particle -- most of a
-        //            quasi-static body -- is done after ONE step; 18 instructions buy back a 65-instruction step.
-        // `far`: the iterate is far from a rotation and the Frobenius scaling pays (it only steers the convergence): with
-        // every singular value in [0.28, 1.6] -- what either test below admits -- the plain iteration is inside the stopping
-        // rule after at most five steps (typical strains: the same two or three steps as the scaled one).  Both decisions are
-        // the lane's own (its result never depends on its wave-mates); the scaling's ~30 instructions, four of them
-        // quarter-rate, are skipped when no lane of the wave asks for them.
-        bool last, far = false;
         float nr = 0.0f;
-        if (it == 0) {
-            float w2 = 0.0f;
-            for (int i = 0; i < 9; ++i) { const float w = cof.m[i] - R.m[i]; w2 += w * w; }
-            last = w2 < 2.0e-8f;
-            far = !(w2 <= 0.25f && fabsf(d - 1.0f) <= 0.5f);
-        } else {
-            for (int i = 0; i < 9; ++i) nr += R.m[i] * R.m[i];
-            last = (nr - 3.0f < 4.0e-4f) && (nr - 3.0f > -1.0e-5f);
-            if (it == 1) far = !(fabsf(nr - 3.0f) <= 0.5f && fabsf(d - 1.0f) <= 0.5f);
-        }
+        for (int i = 0; i < 9; ++i) nr += R.m[i] * R.m[i];
+        // the entering iterate is within 2e-4 of a rotation (valid from the second step on; NaN never is): last step
+        const bool last = (it >= 1) && (nr - 3.0f < 4.0e-4f) && (nr - 3.0f > -1.0e-5f);
         float a = 0.5f, b = 0.5f * inv_d;  // R <- a R + b cof
         if (it < 2) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (__any(far && !settled))
-#else
-            if (far)
-#endif
-            {
-                if (it == 0)
-                    for (int i = 0; i < 9; ++i) nr += R.m[i] * R.m[i];
-                float nc = 0.0f;
-                for (int i = 0; i < 9; ++i) nc += cof.m[i] * cof.m[i];
-                // g^2 = |R^-T|_F / |R|_F = |cof|_F / (|d| |R|_F)   (only steers the convergence: approximate is fine)
-                const float g2 = px_sqrt(nc * px_rcp(nr)) * fabsf(inv_d);
-                const float g = px_sqrt(g2);
-                if (far) {
-                    a = 0.5f * g;
-                    b = 0.5f * inv_d * px_rcp(g);
-                }
-            }
+            float nc = 0.0f;
+            for (int i = 0; i < 9; ++i) nc += cof.m[i] * cof.m[i];
+            // g^2 = |R^-T|_F / |R|_F = |cof|_F / (|d| |R|_F)   (only steers the convergence: approximate is fine)
+            const float g2 = px_sqrt(nc * px_rcp(nr)) * fabsf(inv_d);
+            const float g = px_sqrt(g2);
+            a = 0.5f * g;
+            b = 0.5f * inv_d * px_rcp(g);
         }
-        if (settled) { a = 1.0f; b = 0.0f; }   // a frozen iterate: 1 R + 0 cof is R exactly (R is finite once settled)
-        for (int i = 0; i < 9; ++i) R.m[i] = a * R.m[i] + b * cof.m[i];
+        for (int i = 0; i < 9; ++i) {
+            const float r = a * R.m[i] + b * cof.m[i];
+            if (!settled) R.m[i] = r;
+        }
         if (last) settled = true;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (__all(settled)) break;
+        if (it >= 1 && __all(settled)) break;
 #endif
     }
     return det > 0.0f && settled;

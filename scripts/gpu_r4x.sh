@@ -1,5 +1,6 @@
 #!/bin/bash
-# Polar iteration (mpm_math.h): Frobenius scaling only far from a rotation, and a one-step exit for nearly rigid particles.  MPM GPU
+# (Record of an experiment: the two libraries under scripts/_ab/ were built from the commits named in profiles/r4x_mpm_polar_iteration_variants.txt
+# and are not kept.)  Polar iteration (mpm_math.h): Frobenius scaling only far from a rotation, and a one-step exit for nearly rigid particles.  MPM GPU
 # tests on the new library, then a same-box A/B/C of the step loop, alternating: new library / scripts/_ab/libpixie_hip_noscale.so (the
 # first change only) / scripts/_ab/libpixie_hip_prev.so (built from the parent commit).  PIXIE_MPM_V0=0.6 is a scene in motion (strains of a few per cent).
 OUT=gpurun_out/${1:-r4x}

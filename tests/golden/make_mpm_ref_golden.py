@@ -208,8 +208,8 @@ def long_scenes():
     # The knife edge: a collider plane that COINCIDES with a node plane (plane z = 0.6, dx = 0.1f).  Whether those nodes are "below"
     # it (mpm_solver_warp.py:821-840: dot(x_node - point, normal) < 0) is decided by the last bit of float(k) * dx - point:
     # evaluated in float32 with every operation rounded, 6 * 0.1f rounds to exactly 0.6f and the node plane is NOT in the collider;
-    # evaluated exactly on the same float32 data (float64 here; a fused multiply-add in a float32 build -- what nvcc and hipcc
-    # contract `float(k) * dx - p` into by default) 6 * 0.1f - 0.6f = -1.5e-8 and it IS.  The two evaluations of the reference's
+    # evaluated exactly on the same float32 data (float64 here; a fused multiply-add in a float32 build, which a compiler is free
+    # to contract `float(k) * dx - p` into) 6 * 0.1f - 0.6f = -1.5e-8 and it IS.  The two evaluations of the reference's
     # own source differ by 16 % in v after ONE substep; which one a float32 build gives is the compiler's contraction choice, not
     # the source's.  This scene stores both (`k*_f32/...`) so the tests can say which side an implementation is on.
     # (custom_sand_config.json's own floor, z = 0.48 with dx = 0.01f, is NOT such a case: 48 * 0.01f equals 0.48f exactly.)

@@ -170,10 +170,12 @@ def test_device_stress_matches_oracle(material, scale, ys):
 
 
 def test_polar_iteration_converges_with_and_without_scaling():
-    """polar_rotation (mpm_math.h, host build): the Frobenius scaling is applied only to iterates far from a rotation
-    (|sum s_i^2 - 3| > 0.5 or |det - 1| > 0.5).  Sweep singular values over both regions, the corners of the unscaled one
-    included, and nearly rigid inputs (the one-step exit: |cof F - F|_F^2 < 2e-8): the iteration must settle within its six steps and give the polar factor U V^T to float32 accuracy; det <= 0
-    must be refused (the caller then takes the SVD route)."""
+    """polar_rotation (mpm_math.h, host build) over the whole range it is used on: nearly rigid inputs, the strains of a stable
+    simulation, singular values from 0.15 to 3.  The iteration must settle within its six steps and give the polar factor U V^T
+    to float32 accuracy; det <= 0 must be refused (the caller then takes the SVD route).  (Written for a variant that applied
+    the Frobenius scaling only far from a rotation and left after one step for nearly rigid particles -- `unscaled` below is the
+    region where that variant ran the plain iteration; it was timed equal to this one on the GPU and not kept,
+    profiles/r4x_mpm_polar_iteration_variants.txt.)"""
     lib = _harness.load()
     rng = np.random.default_rng(5)
     def rot(n):
