@@ -918,7 +918,8 @@ def main():
                 m_large["two_scenes"] = {"value": two["value"], "unit": "particle-steps/s", "scenes": 2, "us_per_scene_substep": per_scene_us, "finite": two["finite"],
                                          "frac_dense_grid": m_large["substep_bytes_dense"] / (per_scene_us * 1e-6) / 1e9 / PEAK_HBM_GBPS,
                                          "frac_touched_cells": m_large["substep_bytes_touched"] / (per_scene_us * 1e-6) / 1e9 / PEAK_HBM_GBPS,
-                                         "config": two["config"]}
+                                         "config": two["config"], "timing": two["timing"],
+                                         "repetitions_us_per_scene_substep": [round(r / 2.0, 2) for r in two["repetitions_us_per_substep"]]}
             m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
             six = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 6)
             m_multi["six_scenes"] = {k: six[k] for k in ("value", "unit", "scenes", "us_per_substep_per_scene", "finite")}
