@@ -9,7 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pixie_amd.unet import ACT_LEAKY, HipOps, RegressionUNet, SegmentationUNet, predict_material_field  # noqa: E402
+from pixie_amd.unet import HipOps, RegressionUNet, SegmentationUNet, predict_material_field  # noqa: E402
 from pixie_amd.unet_plan import synthetic_state_dict  # noqa: E402
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -15,7 +15,7 @@ from make_unet_golden import CASES, HEADS  # noqa: E402
 
 from oracle import unet_oracle
 from pixie_amd.synthetic import feature_grid
-from pixie_amd.unet_plan import UNetConfig, synthetic_state_dict
+from pixie_amd.unet_plan import synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
