@@ -252,6 +252,55 @@ PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
     return det > 0.0f && settled;
 }
 
+// ---------------------------------------------------------------- fixed-corotated stress without the rotation (small strain)
+// kirchoff_stress_FCR (mpm_utils.py:10-17) is  tau = 2 mu (F - R) F^T + lam J (J - 1) I  with R the polar rotation of F.
+// For det F > 0:  (F - R) F^T = F F^T - R F^T = b - sqrt(b),  b = F F^T  (R F^T = R S R^T is the left stretch, the symmetric
+// positive square root of b).  With b = I + E:
+//     b - sqrt(b) = E/2 + E^2/8 - E^3/16 + 5 E^4/128 - 7 E^5/256 + O(E^6)      (x - (sqrt(1 + x) - 1), coefficient of x^6: 21/1024)
+// -- a polynomial in ONE symmetric matrix, so every product is symmetric (6 entries, 18 FMAs) and Horner needs four of them: ~125
+// instructions with E, against ~350 for three Newton steps of polar_rotation plus (F - R) F^T.  Truncation error at |E|_F = 0.12 (stretches within ~6 % of 1):
+// 21/1024 x^6 = 6e-8 against x/2 = 0.06 -- 1e-6 relative, the float32 floor; the stress is also free of the F - R cancellation.
+// Valid only for det F > 0 and small E: the caller tests both per lane and takes the rotation route otherwise.
+struct Sym3 {
+    float xx, xy, xz, yy, yz, zz;
+};
+PX_HD Sym3 sym_mul_commuting(const Sym3& a, const Sym3& b) {   // a b for commuting symmetric a, b (the product is symmetric)
+    Sym3 c;
+    c.xx = a.xx * b.xx + a.xy * b.xy + a.xz * b.xz;
+    c.xy = a.xx * b.xy + a.xy * b.yy + a.xz * b.yz;
+    c.xz = a.xx * b.xz + a.xy * b.yz + a.xz * b.zz;
+    c.yy = a.xy * b.xy + a.yy * b.yy + a.yz * b.yz;
+    c.yz = a.xy * b.xz + a.yy * b.yz + a.yz * b.zz;
+    c.zz = a.xz * b.xz + a.yz * b.yz + a.zz * b.zz;
+    return c;
+}
+constexpr float kFcrSeriesMaxE2 = 0.0144f;   // |E|_F <= 0.12
+PX_HD Sym3 fcr_strain(const Mat3& F) {       // E = F F^T - I
+    // The diagonal starts from fma(F_ii, F_ii, -1): exact product, one rounding of a SMALL number when F is near the identity (so E
+    // keeps full relative precision there, where it matters most), and no worse than 1e-7 absolute under a large rotation.
+    Sym3 E;
+    E.xx = fmaf(F.m[2], F.m[2], fmaf(F.m[1], F.m[1], fmaf(F.m[0], F.m[0], -1.0f)));
+    E.yy = fmaf(F.m[5], F.m[5], fmaf(F.m[3], F.m[3], fmaf(F.m[4], F.m[4], -1.0f)));
+    E.zz = fmaf(F.m[7], F.m[7], fmaf(F.m[6], F.m[6], fmaf(F.m[8], F.m[8], -1.0f)));
+    E.xy = fmaf(F.m[2], F.m[5], fmaf(F.m[1], F.m[4], F.m[0] * F.m[3]));
+    E.xz = fmaf(F.m[2], F.m[8], fmaf(F.m[1], F.m[7], F.m[0] * F.m[6]));
+    E.yz = fmaf(F.m[5], F.m[8], fmaf(F.m[4], F.m[7], F.m[3] * F.m[6]));
+    return E;
+}
+PX_HD float sym_norm2(const Sym3& E) {
+    return E.xx * E.xx + E.yy * E.yy + E.zz * E.zz + 2.0f * (E.xy * E.xy + E.xz * E.xz + E.yz * E.yz);
+}
+PX_HD Sym3 fcr_b_minus_sqrt_b(const Sym3& E) {   // E (1/2 + E (1/8 + E (-1/16 + E (5/128 - 7/256 E))))
+    Sym3 h;
+    const float c5 = -7.0f / 256.0f, c4 = 5.0f / 128.0f, c3 = -1.0f / 16.0f, c2 = 0.125f, c1 = 0.5f;
+    h.xx = c5 * E.xx + c4; h.yy = c5 * E.yy + c4; h.zz = c5 * E.zz + c4;
+    h.xy = c5 * E.xy; h.xz = c5 * E.xz; h.yz = c5 * E.yz;
+    h = sym_mul_commuting(E, h); h.xx += c3; h.yy += c3; h.zz += c3;
+    h = sym_mul_commuting(E, h); h.xx += c2; h.yy += c2; h.zz += c2;
+    h = sym_mul_commuting(E, h); h.xx += c1; h.yy += c1; h.zz += c1;
+    return sym_mul_commuting(E, h);
+}
+
 // ---------------------------------------------------------------- constitutive models
 struct MaterialScalars {  // MPMModelStruct scalars, warp_utils.py:24-36
     float alpha, hardening, xi, softening, plastic_viscosity;
@@ -375,7 +424,20 @@ PX_HD Mat3 kirchhoff_stress(int material, const Mat3& F, float mu, float lam, fl
     Mat3 T;
     for (int i = 0; i < 9; ++i) T.m[i] = 0.0f;
     Mat3 Rp;
-    if (material == 6) {
+    Sym3 E;
+    bool series = false;
+    if (material == 0) {
+        E = fcr_strain(F);
+        series = (J > 0.0f) && (sym_norm2(E) <= kFcrSeriesMaxE2);   // the lane's own decision (NaN: false)
+    }
+    if (series) {
+        // fixed-corotated jelly at small strain: 2 mu (b - sqrt b) + lam J (J - 1) I, no rotation needed (see above)
+        const Sym3 P = fcr_b_minus_sqrt_b(E);
+        const float two_mu = 2.0f * mu, iso = lam * J * (J - 1.0f);
+        T.m[0] = two_mu * P.xx + iso; T.m[4] = two_mu * P.yy + iso; T.m[8] = two_mu * P.zz + iso;
+        T.m[1] = T.m[3] = two_mu * P.xy; T.m[2] = T.m[6] = two_mu * P.xz; T.m[5] = T.m[7] = two_mu * P.yz;
+        return T;   // symmetric by construction
+    } else if (material == 6) {
         T = stress_water(J, bulk);
     } else if (material == 0 && polar_rotation(F, Rp)) {
         // fixed-corotated jelly: only the rotation is needed -- Newton polar instead of the full SVD

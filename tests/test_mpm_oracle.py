@@ -206,6 +206,67 @@ def test_polar_iteration_converges_with_and_without_scaling():
     assert not okm.any()
 
 
+def test_fixed_corotated_stress_series_against_float64():
+    """kirchhoff_stress (mpm_math.h, host build), material 0: at small strain (|F F^T - I|_F <= 0.12, det F > 0) the stress
+    2 mu (F - R) F^T + lam J (J - 1) I is evaluated as 2 mu (b - sqrt b), b = F F^T, by a degree-5 polynomial in E = b - I
+    (no rotation, a third of the instructions); above, by the Newton polar iteration as before.  Against the float64 formula
+    with scipy's polar decomposition on the SAME float32 F: under arbitrary rotations the series is several times closer than
+    the rotation route was (6e-8 against 2.8e-7 of 2 mu, absolute), without rotation it keeps full relative precision, and the
+    two routes join without a step at the threshold."""
+    from scipy.linalg import polar
+    lib = _harness.load()
+    rng = np.random.default_rng(0)
+
+    def rot(n):
+        q = np.linalg.qr(rng.normal(size=(n, 3, 3)))[0]
+        return q * np.sign(np.linalg.det(q))[:, None, None]
+
+    def device(F32, mu, lam):
+        n = len(F32)
+        mat = np.zeros(n, np.int32); F = np.zeros((n, 3, 3), np.float32); tau = np.zeros((n, 3, 3), np.float32)
+        muv = np.full(n, mu, np.float32); lamv = np.full(n, lam, np.float32); z = np.zeros(n, np.float32); ys = np.zeros(n, np.float32)
+        lib.hh_stress(n, mat.ctypes.data, F32.ctypes.data, muv.ctypes.data, lamv.ctypes.data, z.ctypes.data, ys.ctypes.data,
+                      0.0, 0.0, 0.0, 0.0, 0.0, 1e-4, F.ctypes.data, tau.ctypes.data)
+        assert np.array_equal(F, F32)
+        return tau
+
+    def truth(F32, mu, lam):
+        out = np.zeros((len(F32), 3, 3))
+        for p, F in enumerate(F32.astype(np.float64)):
+            R, _ = polar(F); J = np.linalg.det(F)
+            out[p] = 2 * mu * (F - R) @ F.T + lam * J * (J - 1) * np.eye(3)
+        return out
+
+    def sample(eps, rotated, n=1500):
+        S = rng.normal(size=(n, 3, 3)); S = (S + S.transpose(0, 2, 1)) / 2
+        S *= eps / np.abs(np.linalg.eigvalsh(S)).max(1)[:, None, None]
+        R = rot(n) if rotated else np.tile(np.eye(3), (n, 1, 1))
+        return np.ascontiguousarray((R @ (np.eye(3) + S)).astype(np.float32))
+
+    mu, lam = 1.0, 0.0                    # the deviatoric part; lam J (J - 1) is common to both routes
+    for eps in (1e-6, 1e-4, 1e-3, 1e-2, 0.03):
+        F32 = sample(eps, True)
+        err = np.abs(device(F32, mu, lam) - truth(F32, mu, lam)).max()
+        assert err < 1.5e-7, (eps, err)                                   # measured 5.8e-8 .. 6.2e-8 (rotation route: 2.4e-7 .. 2.9e-7)
+        F32 = sample(eps, False)
+        tt = truth(F32, mu, lam)
+        rel = np.abs(device(F32, mu, lam) - tt).reshape(len(F32), -1).max(1) / np.abs(tt).reshape(len(F32), -1).max(1)
+        assert rel.max() < 1e-6, (eps, rel.max())                         # measured median 7e-8
+    # across the threshold (|E|_F = 0.12 is a stretch of ~5 %): lanes on either side, same accuracy class, symmetric output
+    F32 = sample(0.05, True, 3000)
+    E = F32.astype(np.float64) @ F32.astype(np.float64).transpose(0, 2, 1) - np.eye(3)
+    small = (E ** 2).sum((1, 2)) <= 0.0144
+    assert 0.2 < small.mean() < 0.8
+    t = device(F32, 1.0, 1.5); tt = truth(F32, 1.0, 1.5)
+    err = np.abs(t - tt).reshape(len(F32), -1).max(1)
+    assert err[small].max() < 6e-7 and err[~small].max() < 1.5e-6         # (the J (J - 1) term in float32 carries ~2e-7 by itself)
+    assert np.array_equal(t, t.transpose(0, 2, 1))
+    # a reflection of a nearly rigid F has b = F F^T ~ I too: it must NOT take the series (det F < 0: the SVD route's convention)
+    Fm = sample(1e-3, True, 200); Fm[:, :, 0] *= -1
+    Fm = np.ascontiguousarray(Fm)
+    assert np.abs(device(Fm, 1.0, 0.0)).max() > 1.0                       # 2 mu (F - R) F^T with a proper R is O(1) there, not O(1e-3)
+
+
 def test_device_stencil_matches_oracle():
     lib = _harness.load()
     rng = np.random.default_rng(3)
