@@ -257,9 +257,11 @@ PX_HD bool polar_rotation(const Mat3& F, Mat3& R) {
 // For det F > 0:  (F - R) F^T = F F^T - R F^T = b - sqrt(b),  b = F F^T  (R F^T = R S R^T is the left stretch, the symmetric
 // positive square root of b).  With b = I + E:
 //     b - sqrt(b) = E/2 + E^2/8 - E^3/16 + 5 E^4/128 - 7 E^5/256 + O(E^6)      (x - (sqrt(1 + x) - 1), coefficient of x^6: 21/1024)
-// -- a polynomial in ONE symmetric matrix, so every product is symmetric (6 entries, 18 FMAs) and Horner needs four of them: ~125
-// instructions with E, against ~350 for three Newton steps of polar_rotation plus (F - R) F^T.  Truncation error at |E|_F = 0.12 (stretches within ~6 % of 1):
-// 21/1024 x^6 = 6e-8 against x/2 = 0.06 -- 1e-6 relative, the float32 floor; the stress is also free of the F - R cancellation.
+// -- a polynomial in ONE symmetric matrix, so every product is symmetric (6 entries, 18 FMAs) and Horner needs four of them.  Measured in
+// the block kernel: 66 VALU instructions per wave fewer than the Newton steps of polar_rotation plus (F - R) F^T (1263 -> 1197,
+// profiles/r4u).  Truncation error at |E|_F = 0.12 (stretches within ~6 % of 1): 21/1024 x^6 = 6e-8 against x/2 = 0.06 -- 1e-6 relative,
+// the float32 floor; and the stress is free of the F - R cancellation: 6e-8 of 2 mu from the float64 value under arbitrary rotations,
+// where the rotation route has 2.8e-7 (tests/test_mpm_oracle.py).
 // Valid only for det F > 0 and small E: the caller tests both per lane and takes the rotation route otherwise.
 struct Sym3 {
     float xx, xy, xz, yy, yz, zz;
