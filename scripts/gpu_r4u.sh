@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Record of an experiment.  The comparison libraries under scripts/_ab/ are not kept: check out the commit named in the matching profiles/ file,
+# run `python -m pixie_amd.build`, and copy pixie_amd/libpixie_hip.so there under the name this script expects.)
 # Fixed-corotated stress from b - sqrt(b) as a polynomial in E = F F^T - I at small strain (mpm_math.h: fcr_b_minus_sqrt_b), no rotation:
 # MPM GPU tests on the new library, same-box alternating timing against the parent commit's library (scripts/_ab/libpixie_hip_prev.so),
 # SQ_INSTS_VALU per wave of both.

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Record of an experiment.  The comparison libraries under scripts/_ab/ are not kept: check out the commit named in the matching profiles/ file,
+# run `python -m pixie_amd.build`, and copy pixie_amd/libpixie_hip.so there under the name this script expects.)
 # Packed fp32 (v_pk_fma_f32) for the x / y components of the regrouped G2P and P2G sums (-DPX_MPM_PK, scripts/_ab/libpixie_hip_pk.so)
 # against the shipped scalar kernel: bit-identity of rollouts (sha256 of the state), the MPM GPU tests on the packed build, and a
 # same-box alternating timing.

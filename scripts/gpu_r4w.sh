@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Record of an experiment.  The comparison libraries under scripts/_ab/ are not kept: check out the commit named in the matching profiles/ file,
+# run `python -m pixie_amd.build`, and copy pixie_amd/libpixie_hip.so there under the name this script expects.)
 # Did the polar-iteration variant (commit 9da2b5a, scripts/_ab/libpixie_hip_polarB.so) execute fewer VALU instructions than the shipped
 # kernel?  SQ_INSTS_VALU / SQ_WAVES / SQ_ACTIVE_INST_VALU of the 1 M step loop under both libraries (counters only: no trace domains).
 OUT=gpurun_out/${1:-r4w}
