@@ -275,101 +275,6 @@ __device__ __forceinline__ void p2g_scatter(const Stencil& st, const float mv[3]
     }
 }
 
-// ---- EXPERIMENT (profiles/r4v_mpm_packed_fp32_xy_rejected.txt; -DPX_MPM_PK): the same two cores with the x and y components of every
-// sum on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two IEEE FMAs per instruction, the weight broadcast to both halves).  Element for
-// element the same operations in the same order as the scalar cores above: results are bit-identical.  1.2 % slower at 1 M.
-typedef float pkf2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pkf2 pk_splat(float w) { return (pkf2){w, w}; }
-__device__ __forceinline__ pkf2 pk_fma(pkf2 a, pkf2 b, pkf2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-template <bool SCHED, class Fetch>
-__device__ __forceinline__ void g2p_gather_pk(const Stencil& st, Fetch fetch, float nv[3], Mat3& B, Mat3& G) {
-    Weights1D wx, wy, wz;
-    weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
-    pkf2 h2[3], t2[3], g02 = pk_splat(0.0f), b02 = pk_splat(0.0f);
-    float hz[3], tz[3], g0z = 0.0f, b0z = 0.0f;
-#pragma unroll
-    for (int o = 0; o < 3; ++o) { h2[o] = pk_splat(0.0f); t2[o] = pk_splat(0.0f); hz[o] = 0.0f; tz[o] = 0.0f; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        pkf2 ss2 = pk_splat(0.0f);
-        float ssz = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float wij = wx.w[i] * wy.w[j];
-            pkf2 s2 = pk_splat(0.0f);
-            float sz = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                pkf2 g2;
-                float gz;
-                fetch(i, j, k, g2, gz);
-                s2 = pk_fma(pk_splat(wz.w[k]), g2, s2);
-                h2[k] = pk_fma(pk_splat(wij), g2, h2[k]);
-                sz = fmaf(wz.w[k], gz, sz);
-                hz[k] = fmaf(wij, gz, hz[k]);
-            }
-            ss2 = pk_fma(pk_splat(wy.w[j]), s2, ss2);
-            t2[j] = pk_fma(pk_splat(wx.w[i]), s2, t2[j]);
-            ssz = fmaf(wy.w[j], sz, ssz);
-            tz[j] = fmaf(wx.w[i], sz, tz[j]);
-        }
-        g02 = pk_fma(pk_splat(wx.dw[i]), ss2, g02);
-        b02 = pk_fma(pk_splat(wx.wd[i]), ss2, b02);
-        g0z = fmaf(wx.dw[i], ssz, g0z);
-        b0z = fmaf(wx.wd[i], ssz, b0z);
-        if (SCHED) __builtin_amdgcn_sched_barrier(0);
-    }
-    auto dot3 = [](const float w[3], const pkf2 v[3]) { return pk_fma(pk_splat(w[2]), v[2], pk_fma(pk_splat(w[1]), v[1], pk_splat(w[0]) * v[0])); };
-    auto dot3z = [](const float w[3], const float v[3]) { return fmaf(w[2], v[2], fmaf(w[1], v[1], w[0] * v[0])); };
-    const pkf2 nv2 = dot3(wz.w, h2), G12 = dot3(wy.dw, t2), B12 = dot3(wy.wd, t2), G22 = dot3(wz.dw, h2), B22 = dot3(wz.wd, h2);
-    nv[0] = nv2.x; nv[1] = nv2.y; nv[2] = dot3z(wz.w, hz);
-    G.m[0] = g02.x; G.m[3] = g02.y; G.m[6] = g0z;
-    B.m[0] = b02.x; B.m[3] = b02.y; B.m[6] = b0z;
-    G.m[1] = G12.x; G.m[4] = G12.y; G.m[7] = dot3z(wy.dw, tz);
-    B.m[1] = B12.x; B.m[4] = B12.y; B.m[7] = dot3z(wy.wd, tz);
-    G.m[2] = G22.x; G.m[5] = G22.y; G.m[8] = dot3z(wz.dw, hz);
-    B.m[2] = B22.x; B.m[5] = B22.y; B.m[8] = dot3z(wz.wd, hz);
-}
-
-template <bool SCHED, class Emit>
-__device__ __forceinline__ void p2g_scatter_pk(const Stencil& st, const float mv[3], const Mat3& A, const Mat3& T, float mass, Emit emit) {
-    Weights1D wx, wy, wz;
-    weights_1d(st, 0, wx); weights_1d(st, 1, wy); weights_1d(st, 2, wz);
-    const pkf2 mv2 = {mv[0], mv[1]};
-    pkf2 A2[3], T2[3];   // [column b] = (row x, row y)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { A2[b] = (pkf2){A.m[b], A.m[3 + b]}; T2[b] = (pkf2){T.m[b], T.m[3 + b]}; }
-    pkf2 U2[3], S2[3];
-    float Uz[3], Sz[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        U2[o] = pk_fma(A2[1], pk_splat(wy.wd[o]), T2[1] * pk_splat(wy.dw[o]));
-        S2[o] = pk_fma(A2[2], pk_splat(wz.wd[o]), T2[2] * pk_splat(wz.dw[o]));
-        Uz[o] = fmaf(A.m[7], wy.wd[o], T.m[7] * wy.dw[o]);
-        Sz[o] = fmaf(A.m[8], wz.wd[o], T.m[8] * wz.dw[o]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const pkf2 E2 = pk_fma(A2[0], pk_splat(wx.wd[i]), pk_fma(T2[0], pk_splat(wx.dw[i]), pk_splat(wx.w[i]) * mv2));
-        const float Ez = fmaf(A.m[6], wx.wd[i], fmaf(T.m[6], wx.dw[i], wx.w[i] * mv[2]));
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float wij = wx.w[i] * wy.w[j];
-            const pkf2 P2 = pk_fma(E2, pk_splat(wy.w[j]), pk_splat(wx.w[i]) * U2[j]);
-            const float Pz = fmaf(Ez, wy.w[j], wx.w[i] * Uz[j]);
-            const float M = wij * mass;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const pkf2 m2 = pk_fma(pk_splat(wz.w[k]), P2, pk_splat(wij) * S2[k]);
-                const float mom[3] = {m2.x, m2.y, fmaf(wz.w[k], Pz, wij * Sz[k])};
-                emit(i, j, k, mom, wz.w[k] * M);
-            }
-        }
-        if (SCHED) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // ---- slow path: a particle whose stencil lies outside its workgroup's tile talks to HBM directly.  Rare
 // (stale binning only), so it is kept out of line and rolled to stay out of the fast path's register budget.
 __device__ __noinline__ void g2p_gather_global(const float4* __restrict__ gout, int ng, Stencil st, float* nv9 /* nv[3], B[9], G[9] */) {
@@ -495,15 +400,6 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
         if ((unsigned)lx <= (unsigned)(kTS - 3) && (unsigned)ly <= (unsigned)(kTS - 3) && (unsigned)lz <= (unsigned)(kTS - 3)) {
             const int b0 = (lx * kTS + ly) * kTS + lz;
-#ifdef PX_MPM_PK
-            typedef float pkf4 __attribute__((ext_vector_type(4)));
-            const pkf4* tvv = reinterpret_cast<const pkf4*>(tv);
-            g2p_gather_pk<SCHED>(st, [&](int i, int j, int k, pkf2& g2, float& gz) {
-                const pkf4 q = tvv[b0 + (i * kTS + j) * kTS + k];
-                asm volatile("" :: "v"(q.w));
-                g2 = q.xy; gz = q.z;
-            }, nv, B, G);
-#else
             g2p_gather<SCHED>(st, [&](int i, int j, int k, float g[3]) {
                 // One ds_read_b128 per node.  The .w lane is dead, but a 16-byte LDS read costs 4 LDS cycles per wave against
                 // 8 for the 12-byte ds_read_b96 the compiler would narrow it to (MI355X_MICROARCH.md, LDS table), and LDS
@@ -512,7 +408,6 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
                 asm volatile("" :: "v"(q.w));
                 g[0] = q.x; g[1] = q.y; g[2] = q.z;
             }, nv, B, G);
-#endif
         } else {
             atomicAdd(S.oob + 1, 1ull);
             float acc[21];
@@ -817,11 +712,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         for (int a = 0; a < 3; ++a) in.mv[a] *= sP;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { in.A.m[k] *= sP; in.T.m[k] *= sP; }
-#ifdef PX_MPM_PK
-        p2g_scatter_pk<SCHED>(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
-#else
         p2g_scatter<SCHED>(st, in.mv, in.A, in.T, in.mass * sM, [&](int i, int j, int k, const float mom[3], float m) {
-#endif
             const int idx = b0 + (i * kTS + j) * kTS + k;
             if (TRACE && (sp.trace & 0x100)) { asm volatile("" :: "v"(mom[0]), "v"(mom[1]), "v"(mom[2]), "v"(m)); return; }
             if (PACK) {
