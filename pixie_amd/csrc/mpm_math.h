@@ -18,6 +18,10 @@
 #define PX_HD inline
 #endif
 
+#ifndef PX_SVD_NEWTON_SCHULZ
+#define PX_SVD_NEWTON_SCHULZ 0
+#endif
+
 namespace pixie {
 
 struct Mat3 {
@@ -85,30 +89,57 @@ PX_HD float px_rsqrt(float x) {
     return 1.0f / sqrtf(x);
 #endif
 }
+// The bare hardware instructions for arguments known to be normal numbers (1 ulp each; the library forms wrap them in
+// denormal scaling and extended-precision range reduction, ~10 VALU instructions apiece in a VALU-issue-bound kernel):
+// v_rsq_f32, a * v_rcp_f32(b), v_log_f32 * ln 2, v_exp_f32(x * log2 e).  IEEE on the host build.
+PX_HD float px_rsq_normal(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+PX_HD float px_div(float a, float b) { return a * px_rcp(b); }
+PX_HD float px_log(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __logf(x);
+#else
+    return logf(x);
+#endif
+}
+PX_HD float px_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
 
-// One Jacobi rotation on the symmetric matrix S (upper storage s00,s01,s02,s11,s12,s22 as a
-// full Mat3) annihilating S(p,q), accumulated into V.
+// One Jacobi rotation on the symmetric matrix S (full Mat3 storage) annihilating S(P,Q), accumulated into V.
+// The angle comes from v_sqrt_f32 / v_rcp_f32 (1 ulp): an inexact angle only slows the convergence of a self-correcting
+// iteration, while c^2 + s^2 = 1 -- what the orthogonality of V rests on -- holds to the accuracy of the one v_rsq_f32.
+// (IEEE sqrtf and '/' cost ~10 VALU instructions each on gfx950; this kernel is VALU-issue bound.)
+// `frozen` lanes (converged earlier) pass through bit-for-bit: t = 0 gives c = 1, s = 0 and every update is x*1 - y*0.
 template <int P, int Q>
-PX_HD void jacobi_rotate(Mat3& S, Mat3& V) {
+PX_HD void jacobi_rotate(Mat3& S, Mat3& V, bool frozen = false) {
     const float apq = S(P, Q);
     const float app = S(P, P), aqq = S(Q, Q);
-    // theta = (aqq-app)/(2apq); t = sgn(theta)/(|theta|+sqrt(theta^2+1)), written without the
-    // division by apq so that apq -> 0 gives t -> 0 smoothly.
+    // theta = (aqq-app)/(2apq); t = sgn(theta)/(|theta|+sqrt(theta^2+1)) = 2apq / (d + sgn(d) sqrt(d^2 + (2apq)^2)), |t| <= 1
     const float d = aqq - app;
     const float two_apq = 2.0f * apq;
-    const float h = sqrtf(d * d + two_apq * two_apq);
-    // t = 2apq / (d + sign(d) h)
-    const float denom = d + (d >= 0.0f ? h : -h);
-    float t = (fabsf(denom) > 1e-30f) ? two_apq / denom : 0.0f;
-    if (fabsf(apq) <= 1e-12f * (fabsf(app) + fabsf(aqq))) t = 0.0f;
-    const float c = px_rsqrt(t * t + 1.0f);
+    const float h = px_sqrt(d * d + two_apq * two_apq);
+    const float denom = d + copysignf(h, d);
+    float t = two_apq * px_rcp(denom);
+    // negligible off-diagonal (also: 0/0 when d = apq = 0, and NaN input): no rotation
+    if (frozen || !(fabsf(apq) > 1e-12f * (fabsf(app) + fabsf(aqq)))) t = 0.0f;
+    const float c = (t == 0.0f) ? 1.0f : px_rsq_normal(t * t + 1.0f);   // argument in [1, 2]
     const float s = t * c;
     // S <- J^T S J with J = [[c, s],[-s, c]] on (P,Q)
     constexpr int R = 3 - P - Q;
     const float arp = S(R, P), arq = S(R, Q);
     S(P, P) = app - t * apq;
     S(Q, Q) = aqq + t * apq;
-    S(P, Q) = 0.0f; S(Q, P) = 0.0f;
+    if (!frozen) { S(P, Q) = 0.0f; S(Q, P) = 0.0f; }
     const float nrp = c * arp - s * arq;
     const float nrq = s * arp + c * arq;
     S(R, P) = nrp; S(P, R) = nrp;
@@ -134,21 +165,44 @@ PX_HD void cond_swap_cols(bool doit, Mat3& B, Mat3& V, float& na, float& nb, int
 // 3x3 SVD in the convention the reference relies on from wp.svd3 (Warp built-in, called at
 // mpm_utils.py:94,145,202,249,501,566): F = U diag(sig) V^T with U, V proper rotations,
 // |sig0| >= |sig1| >= |sig2| and only sig2 allowed to be negative (sign(sig2) = sign(det F)).
-PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
+//
+// Cyclic Jacobi on F^T F, sweeps until THIS lane's off-diagonal mass is below float32 resolution
+// (off^2 <= 1e-14 tr^2: a reconstruction error of 1e-7 |F|, singular values second order in it), at most kSvdSweeps.
+// A lane freezes at its own last sweep, so its result does not depend on which other particles share its wave; the wave
+// leaves the loop when every lane has frozen -- 2 sweeps for the strains of a stable simulation, 3 for anything else
+// that is not pathological (tests/test_mpm_oracle.py prints the histogram).
+constexpr int kSvdSweeps = 6;
+PX_HD bool svd_converged(const Mat3& S) {
+    const float off2 = S(0, 1) * S(0, 1) + S(0, 2) * S(0, 2) + S(1, 2) * S(1, 2);
+    const float tr = S(0, 0) + S(1, 1) + S(2, 2);
+    return !(off2 > 1.0e-14f * tr * tr);   // NaN counts as converged (nothing sensible can be done with it)
+}
+PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V, int* sweeps_out = nullptr) {
     Mat3 S;  // F^T F
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) S(i, j) = F(0, i) * F(0, j) + F(1, i) * F(1, j) + F(2, i) * F(2, j);
     V = mat_identity();
+    bool frozen = svd_converged(S);
+    int sweeps = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
+#pragma unroll 1
 #endif
-    for (int sweep = 0; sweep < 5; ++sweep) {
-        jacobi_rotate<0, 1>(S, V);
-        jacobi_rotate<0, 2>(S, V);
-        jacobi_rotate<1, 2>(S, V);
+    for (int sweep = 0; sweep < kSvdSweeps; ++sweep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__all(frozen)) break;
+#else
+        if (frozen) break;
+#endif
+        jacobi_rotate<0, 1>(S, V, frozen);
+        jacobi_rotate<0, 2>(S, V, frozen);
+        jacobi_rotate<1, 2>(S, V, frozen);
+        if (!frozen) ++sweeps;
+        frozen = frozen || svd_converged(S);
     }
-    // 15 accumulated fp32 rotations leave V orthogonal only to ~1e-6; one Newton-Schulz step
-    // V <- V (3I - V^T V)/2 squares that error, which keeps R = U V^T accurate to fp32 roundoff.
+    if (sweeps_out) *sweeps_out = sweeps;
+#if PX_SVD_NEWTON_SCHULZ
+    // accumulated fp32 rotations leave V orthogonal only to a few 1e-7; one Newton-Schulz step
+    // V <- V (3I - V^T V)/2 squares that error.
     {
         Mat3 G;
         for (int i = 0; i < 3; ++i)
@@ -158,6 +212,7 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
             }
         V = mat_mul(V, G);
     }
+#endif
     Mat3 B = mat_mul(F, V);
     float n0 = B(0, 0) * B(0, 0) + B(1, 0) * B(1, 0) + B(2, 0) * B(2, 0);
     float n1 = B(0, 1) * B(0, 1) + B(1, 1) * B(1, 1) + B(2, 1) * B(2, 1);
@@ -190,6 +245,58 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V) {
     sig[0] = u0[0] * B(0, 0) + u0[1] * B(1, 0) + u0[2] * B(2, 0);
     sig[1] = u1[0] * B(0, 1) + u1[1] * B(1, 1) + u1[2] * B(2, 1);
     sig[2] = u2[0] * B(0, 2) + u2[1] * B(1, 2) + u2[2] * B(2, 2);
+}
+
+// Left principal frame of F, the only part of the SVD the constitutive laws need:  F F^T = U diag(sig^2) U^T  by the same
+// cyclic Jacobi iteration run on b = F F^T (accumulating U), sig_d = sqrt(lam_d), U a proper rotation, axes UNSORTED.
+// For det F < 0 the sign goes to the singular value of smallest magnitude -- Warp's convention (see svd3), the one thing of
+// the ordering that matters to callers: every law downstream is a function of the (sig_d, u_d) pairs and invariant under
+// their permutation.  Against svd3 this drops the V accumulation's aftermath (B = F V, the column norms, the sort, the
+// Gram-Schmidt U): ~170 of ~630 VALU instructions.  det_F = det F (the caller has it anyway).
+PX_HD void left_stretch(const Mat3& F, float det_F, Mat3& U, float sig[3], int* sweeps_out = nullptr) {
+    Mat3 S;  // F F^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            const float v = F(i, 0) * F(j, 0) + F(i, 1) * F(j, 1) + F(i, 2) * F(j, 2);
+            S(i, j) = v; S(j, i) = v;
+        }
+    U = mat_identity();
+    bool frozen = svd_converged(S);
+    int sweeps = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int sweep = 0; sweep < kSvdSweeps; ++sweep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__all(frozen)) break;
+#else
+        if (frozen) break;
+#endif
+        jacobi_rotate<0, 1>(S, U, frozen);
+        jacobi_rotate<0, 2>(S, U, frozen);
+        jacobi_rotate<1, 2>(S, U, frozen);
+        if (!frozen) ++sweeps;
+        frozen = frozen || svd_converged(S);
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    const float l0 = S(0, 0), l1 = S(1, 1), l2 = S(2, 2);
+    sig[0] = px_sqrt(fmaxf(l0, 0.0f)); sig[1] = px_sqrt(fmaxf(l1, 0.0f)); sig[2] = px_sqrt(fmaxf(l2, 0.0f));
+    // An eigenvalue of F F^T carries an absolute error of ~1e-7 lam_max, i.e. sig_d one of 1e-7 lam_max / sig_d: fine while the
+    // stretches are within a factor 2 of each other (every stable simulation), not for a crushed element.  There (rare,
+    // the lane's own test) sig_d = |F^T u_d| instead: a sum of squares, accurate relative to sig_d itself.
+    if (fminf(fminf(l0, l1), l2) < 0.25f * fmaxf(fmaxf(l0, l1), l2)) {
+        for (int d = 0; d < 3; ++d) {
+            const float a0 = F(0, 0) * U(0, d) + F(1, 0) * U(1, d) + F(2, 0) * U(2, d);
+            const float a1 = F(0, 1) * U(0, d) + F(1, 1) * U(1, d) + F(2, 1) * U(2, d);
+            const float a2 = F(0, 2) * U(0, d) + F(1, 2) * U(1, d) + F(2, 2) * U(2, d);
+            sig[d] = px_sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+        }
+    }
+    if (det_F < 0.0f) {
+        if (l0 <= l1 && l0 <= l2) sig[0] = -sig[0];
+        else if (l1 <= l2) sig[1] = -sig[1];
+        else sig[2] = -sig[2];
+    }
 }
 
 // Rotation factor R of the polar decomposition F = R S by the scaled Newton iteration
@@ -308,37 +415,8 @@ struct MaterialScalars {  // MPMModelStruct scalars, warp_utils.py:24-36
     float alpha, hardening, xi, softening, plastic_viscosity;
 };
 
-PX_HD float vlen3(float a, float b, float c) { return sqrtf(a * a + b * b + c * c); }
+PX_HD float vlen3(float a, float b, float c) { return px_sqrt(a * a + b * b + c * c); }
 
-// kirchoff_stress_FCR, mpm_utils.py:10-17:  2 mu (F - R) F^T + lam J (J-1) I
-PX_HD Mat3 stress_fcr(const Mat3& F, const Mat3& U, const Mat3& V, float J, float mu, float lam) {
-    Mat3 R = mat_mul_bt(U, V);
-    Mat3 D;
-    for (int i = 0; i < 9; ++i) D.m[i] = 2.0f * mu * (F.m[i] - R.m[i]);
-    Mat3 T = mat_mul_bt(D, F);
-    const float iso = lam * J * (J - 1.0f);
-    T.m[0] += iso; T.m[4] += iso; T.m[8] += iso;
-    return T;
-}
-// kirchoff_stress_StVK, mpm_utils.py:52-68
-PX_HD Mat3 stress_stvk(const Mat3& F, const Mat3& U, const Mat3& V, const float sig_in[3], float mu, float lam) {
-    float e[3], tau[3];
-    for (int d = 0; d < 3; ++d) e[d] = logf(fmaxf(sig_in[d], 0.01f));
-    const float tr = e[0] + e[1] + e[2];
-    for (int d = 0; d < 3; ++d) tau[d] = 2.0f * mu * e[d] + lam * tr;
-    return mat_mul_bt(mat_udvt(U, tau, V), F);
-}
-// kirchoff_stress_drucker_prager, mpm_utils.py:71-86
-PX_HD Mat3 stress_dp(const Mat3& F, const Mat3& U, const Mat3& V, const float sig[3], float mu, float lam) {
-    float l[3], c[3];
-    for (int d = 0; d < 3; ++d) l[d] = logf(sig[d]);
-    const float tr = l[0] + l[1] + l[2];
-    for (int d = 0; d < 3; ++d) {
-        const float inv = 1.0f / sig[d];
-        c[d] = 2.0f * mu * l[d] * inv + lam * tr * inv;
-    }
-    return mat_mul_bt(mat_udvt(U, c, V), F);
-}
 // kirchoff_stress_water, mpm_utils.py:20-28
 PX_HD Mat3 stress_water(float J, float bulk) {
     const float pressure = -bulk * (powf(J, -1.1f) - 1.0f);
@@ -348,79 +426,156 @@ PX_HD Mat3 stress_water(float J, float bulk) {
     return T;
 }
 
-// von_mises_return_mapping (mpm_utils.py:89-135) and ..._with_damage (:138-191).
-// ys/mu/lam are the particle's mutable model entries.
-PX_HD Mat3 rm_von_mises(const Mat3& Ft, float& ys, float& mu, float& lam, const MaterialScalars& ms, bool damage) {
-    Mat3 U, V;
-    float so[3];
-    svd3(Ft, U, so, V);
-    float e[3];
-    for (int d = 0; d < 3; ++d) e[d] = logf(fmaxf(so[d], 0.01f));
-    const float tr = e[0] + e[1] + e[2];
-    const float temp = tr / 3.0f;
-    float tau[3];
-    for (int d = 0; d < 3; ++d) tau[d] = 2.0f * mu * e[d] + lam * tr;
-    const float st = tau[0] + tau[1] + tau[2];
-    const float cn = vlen3(tau[0] - st / 3.0f, tau[1] - st / 3.0f, tau[2] - st / 3.0f);
-    if (cn > ys) {
-        if (damage && ys <= 0.0f) return Ft;
-        const float eh[3] = {e[0] - temp, e[1] - temp, e[2] - temp};
-        const float ehn = vlen3(eh[0], eh[1], eh[2]) + 1e-6f;
-        const float dg = ehn - ys / (2.0f * mu);
-        const float k = dg / ehn;
-        float ex[3];
-        for (int d = 0; d < 3; ++d) ex[d] = expf(e[d] - k * eh[d]);
-        if (damage) {
-            ys = ys - ms.softening * vlen3(k * eh[0], k * eh[1], k * eh[2]);
-            if (ys <= 0.0f) { mu = 0.0f; lam = 0.0f; }
-        }
-        Mat3 Fe = mat_udvt(U, ex, V);
-        if (ms.hardening == 1.0f) ys = ys + 2.0f * mu * ms.xi * dg;
-        return Fe;
+// ---- everything that goes through the SVD: ONE decomposition per particle, and only its left half ---------------------
+// The reference decomposes twice: F_trial inside the return mapping (mpm_utils.py:94,145,202,249) and the returned F again
+// for the stress (:501).  The second one decomposes a matrix whose factors are already in hand:
+//   * no yield:  F = F_trial, same U, sigma, V;
+//   * yield:     F = U diag(sigma') V^T was just ASSEMBLED from proper rotations and positive sigma' (:115-124 etc.), so its
+//     SVD is (U P, P^T sigma', V P) for a permutation P -- and every stress law below is invariant under P.
+// Every stress of the SVD family has the form  P F^T  with  P = U diag(p) V^T  (:17 with R = U V^T, :63-68, :86), so with
+// F^T = V diag(sigma) U^T it collapses to  tau = U diag(t) U^T,  t_d = p_d sigma_d:
+//   fixed-corotated (0, 5):  t_d = 2 mu (sigma_d - 1) sigma_d + lam J (J - 1)
+//   StVK-Hencky (1, 3):      t_d = (2 mu eps_d + lam tr eps) sigma_d,   eps_d = log max(sigma_d, 0.01)
+//   Drucker-Prager (2):      t_d = (2 mu log sigma_d + lam tr log sigma) / sigma_d * sigma_d
+// -- symmetric by construction (the reference's (T + T^T)/2 is the identity on it) and free of the F - R cancellation.
+// The returned F needs no V either:  U diag(sigma') V^T = U diag(sigma'/sigma) U^T F_trial, written as the CORRECTION
+//     F = F_trial + (U diag(sigma'_d/sigma_d - 1) U^T) F_trial,      sigma'_d/sigma_d = exp(eps'_d - eps_d)
+// so a particle that yields a little moves F a little (the re-assembly from three factors re-rounds every entry of F at
+// 1e-7 whether it moved or not).  So the decomposition is left_stretch: Jacobi on F F^T, U and sigma only.
+// A wave whose lanes hold different plastic materials runs it once for all of them; only the three-scalar return maps
+// diverge.  tests/test_mpm_oracle.py holds this against the tests' two-SVD restatement of the reference (itself pinned to
+// the reference's code, tests/test_mpm_ref_golden.py).
+constexpr float kLogSigMin = -4.605170186f;   // log(0.01): the clamp of :98,:149,:206 and :57 in log space
+
+PX_HD bool is_svd_material(int material) { return material == 1 || material == 2 || material == 3 || material == 5; }
+
+// one returned singular value: sigma' = exp(e_new) and sigma'/sigma - 1, from the log-space step e_new - e when e is the log
+// of sigma itself (sigma >= floor > 0: one exp, the step keeps its relative accuracy), from the values otherwise (clamped
+// or inverted sigma: the reference's exp of the clamped strain against the raw sigma)
+PX_HD void returned_sigma(float so, float e, float e_new, float floor_, float& sn, float& rm1) {
+    if (so >= floor_) {
+        const float r = px_exp(e_new - e);
+        rm1 = r - 1.0f;
+        sn = so * r;
+    } else {
+        sn = px_exp(e_new);
+        rm1 = px_div(sn, so) - 1.0f;
     }
-    return Ft;
-}
-// viscoplasticity_return_mapping_with_StVK, mpm_utils.py:195-239
-PX_HD Mat3 rm_visco(const Mat3& Ft, float ys, float mu, const MaterialScalars& ms, float dt) {
-    Mat3 U, V;
-    float so[3], sg[3], e[3];
-    svd3(Ft, U, so, V);
-    for (int d = 0; d < 3; ++d) { sg[d] = fmaxf(so[d], 0.01f); e[d] = logf(sg[d]); }
-    const float tr = e[0] + e[1] + e[2];
-    const float eh[3] = {e[0] - tr / 3.0f, e[1] - tr / 3.0f, e[2] - tr / 3.0f};
-    const float s[3] = {2.0f * mu * eh[0], 2.0f * mu * eh[1], 2.0f * mu * eh[2]};
-    const float sn = vlen3(s[0], s[1], s[2]);
-    const float y = sn - sqrtf(2.0f / 3.0f) * ys;
-    if (y > 0.0f) {
-        const float mu_hat = mu * (sg[0] * sg[0] + sg[1] * sg[1] + sg[2] * sg[2]) / 3.0f;
-        const float snn = sn - y / (1.0f + ms.plastic_viscosity / (2.0f * mu_hat * dt));
-        float ex[3];
-        for (int d = 0; d < 3; ++d) ex[d] = expf(1.0f / (2.0f * mu) * ((snn / sn) * s[d]) + tr / 3.0f);
-        return mat_udvt(U, ex, V);
-    }
-    return Ft;
-}
-// sand_return_mapping, mpm_utils.py:242-279
-PX_HD Mat3 rm_sand(const Mat3& Ft, float mu, float lam, const MaterialScalars& ms) {
-    Mat3 U, V;
-    float sg[3], e[3];
-    svd3(Ft, U, sg, V);
-    for (int d = 0; d < 3; ++d) e[d] = logf(fmaxf(fabsf(sg[d]), 1e-14f));
-    const float tr = e[0] + e[1] + e[2];
-    const float eh[3] = {e[0] - tr / 3.0f, e[1] - tr / 3.0f, e[2] - tr / 3.0f};
-    const float ehn = vlen3(eh[0], eh[1], eh[2]);
-    const float dg = ehn + (3.0f * lam + 2.0f * mu) / (2.0f * mu) * tr * ms.alpha;
-    if (dg <= 0.0f) return Ft;
-    if (tr > 0.0f) return mat_mul_bt(U, V);
-    float ex[3];
-    for (int d = 0; d < 3; ++d) ex[d] = expf(e[d] - eh[d] * (dg / ehn));
-    return mat_udvt(U, ex, V);
 }
 
-// Constitutive half of compute_stress_from_F_trial (mpm_utils.py:495-526): Kirchhoff stress of the
-// (already return-mapped) F, symmetrised.  Material ids (mpm_solver_warp.py:10-18): 0 jelly, 1 metal,
-// 2 sand, 3 visplas, 5 snow, 6 "stationary" -- which the reference treats as the water EOS with `bulk`
-// (0 in every shipped flow => tau = 0); any other id gives tau = 0.
+// Return mapping of the singular values `so` of F_trial (signed, Warp convention; any order) for material 1 / 2 / 3 / 5 and
+// the principal Kirchhoff stresses t of the returned F.  Returns true when F moved:  F = F_trial + U diag(rm1) U^T F_trial
+// with singular values sn; false: F = F_trial (sn = so, rm1 = 0).  J_trial = det F_trial.
+// mu / lam / ys are the particle's mutable model entries (snow damage, hardening).
+PX_HD bool return_map_principal(int material, const float so[3], float J_trial, float& mu, float& lam, float& ys,
+                                const MaterialScalars& ms, float dt, float sn[3], float rm1[3], float t[3]) {
+    bool moved = false;
+    for (int d = 0; d < 3; ++d) { sn[d] = so[d]; rm1[d] = 0.0f; }
+    if (material == 2) {
+        // sand_return_mapping, mpm_utils.py:242-279 + kirchoff_stress_drucker_prager, :71-86
+        float e[3];
+        for (int d = 0; d < 3; ++d) e[d] = px_log(fmaxf(fabsf(so[d]), 1e-14f));
+        const float tr = e[0] + e[1] + e[2];
+        const float eh[3] = {e[0] - tr * (1.0f / 3.0f), e[1] - tr * (1.0f / 3.0f), e[2] - tr * (1.0f / 3.0f)};
+        const float ehn = vlen3(eh[0], eh[1], eh[2]);
+        const float dg = ehn + px_div(3.0f * lam + 2.0f * mu, 2.0f * mu) * tr * ms.alpha;
+        float l[3] = {e[0], e[1], e[2]};            // log of the returned F's singular values
+        if (dg > 0.0f) {
+            moved = true;
+            const float k = (tr > 0.0f) ? 0.0f : px_div(dg, ehn);
+            for (int d = 0; d < 3; ++d) {
+                l[d] = (tr > 0.0f) ? 0.0f : e[d] - eh[d] * k;   // expansion: F = U V^T (sigma' = 1), stress-free
+                returned_sigma(so[d], e[d], l[d], 1e-14f, sn[d], rm1[d]);
+            }
+        } else if (!(fminf(fminf(so[0], so[1]), so[2]) >= 1e-14f)) {
+            // elastic with a collapsed / inverted element: the reference takes log(sigma) of the raw value (:75), NaN for < 0
+            for (int d = 0; d < 3; ++d) l[d] = px_log(so[d]);
+        }
+        const float ltr = l[0] + l[1] + l[2];
+        for (int d = 0; d < 3; ++d) t[d] = 2.0f * mu * l[d] + lam * ltr;
+        return moved;
+    }
+    // 1 metal, 3 visco-plastic, 5 snow: Hencky strain of the clamped singular values (:98-101, :149-152, :206-211)
+    float e[3], en[3];
+    for (int d = 0; d < 3; ++d) e[d] = en[d] = px_log(fmaxf(so[d], 0.01f));
+    const float tr = e[0] + e[1] + e[2];
+    const float eh[3] = {e[0] - tr * (1.0f / 3.0f), e[1] - tr * (1.0f / 3.0f), e[2] - tr * (1.0f / 3.0f)};
+    if (material == 3) {
+        // viscoplasticity_return_mapping_with_StVK, :195-239
+        const float two_mu = 2.0f * mu;
+        const float sn_ = two_mu * vlen3(eh[0], eh[1], eh[2]);            // |s_trial|
+        const float y = sn_ - 0.8164965809f * ys;
+        if (y > 0.0f) {
+            float b = 0.0f;
+            for (int d = 0; d < 3; ++d) { const float sg = fmaxf(so[d], 0.01f); b += sg * sg; }
+            const float mu_hat = mu * b * (1.0f / 3.0f);
+            const float snn = sn_ - px_div(y, 1.0f + px_div(ms.plastic_viscosity, 2.0f * mu_hat * dt));
+            for (int d = 0; d < 3; ++d) en[d] = px_rcp(two_mu) * (px_div(snn, sn_) * (two_mu * eh[d])) + tr * (1.0f / 3.0f);
+            moved = true;
+        }
+    } else {
+        // von_mises_return_mapping (:89-135) / ..._with_damage (:138-191)
+        const bool damage = (material == 5);
+        float tau[3];
+        for (int d = 0; d < 3; ++d) tau[d] = 2.0f * mu * e[d] + lam * tr;
+        const float st = tau[0] + tau[1] + tau[2];
+        const float cn = vlen3(tau[0] - st * (1.0f / 3.0f), tau[1] - st * (1.0f / 3.0f), tau[2] - st * (1.0f / 3.0f));
+        if (cn > ys && !(damage && ys <= 0.0f)) {
+            const float ehn = vlen3(eh[0], eh[1], eh[2]) + 1e-6f;
+            const float dg = ehn - px_div(ys, 2.0f * mu);
+            const float k = px_div(dg, ehn);
+            for (int d = 0; d < 3; ++d) en[d] = e[d] - k * eh[d];
+            if (damage) {
+                ys = ys - ms.softening * vlen3(k * eh[0], k * eh[1], k * eh[2]);
+                if (ys <= 0.0f) { mu = 0.0f; lam = 0.0f; }
+            }
+            if (ms.hardening == 1.0f) ys = ys + 2.0f * mu * ms.xi * dg;
+            moved = true;
+        }
+    }
+    if (moved)
+        for (int d = 0; d < 3; ++d) returned_sigma(so[d], e[d], en[d], 0.01f, sn[d], rm1[d]);
+    if (material == 5) {
+        // kirchoff_stress_FCR (:10-17) in principal form; J of the returned F
+        const float J = moved ? sn[0] * sn[1] * sn[2] : J_trial;
+        const float iso = lam * J * (J - 1.0f);
+        for (int d = 0; d < 3; ++d) t[d] = 2.0f * mu * (sn[d] - 1.0f) * sn[d] + iso;
+    } else {
+        // kirchoff_stress_StVK (:52-68): the strain of the returned F, clamped as the stress function clamps it
+        float ec[3];
+        for (int d = 0; d < 3; ++d) ec[d] = moved ? fmaxf(en[d], kLogSigMin) : e[d];
+        const float etr = ec[0] + ec[1] + ec[2];
+        for (int d = 0; d < 3; ++d) t[d] = (2.0f * mu * ec[d] + lam * etr) * sn[d];
+    }
+    return moved;
+}
+
+// U diag(d) U^T, symmetric
+PX_HD Mat3 mat_udut(const Mat3& U, const float d[3]) {
+    Mat3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            const float v = U.m[3 * i] * d[0] * U.m[3 * j] + U.m[3 * i + 1] * d[1] * U.m[3 * j + 1] + U.m[3 * i + 2] * d[2] * U.m[3 * j + 2];
+            r.m[3 * i + j] = v;
+            r.m[3 * j + i] = v;
+        }
+    return r;
+}
+
+// fixed-corotated stress by the decomposition route (inverted or badly conditioned jelly): principal form of mpm_utils.py:10-17
+PX_HD Mat3 stress_fcr_svd(const Mat3& F, float J, float mu, float lam) {
+    Mat3 U;
+    float sg[3], t[3];
+    left_stretch(F, J, U, sg);
+    const float iso = lam * J * (J - 1.0f);
+    for (int d = 0; d < 3; ++d) t[d] = 2.0f * mu * (sg[d] - 1.0f) * sg[d] + iso;
+    return mat_udut(U, t);
+}
+
+// Stress of a GIVEN elastic F (the export path, mpm_solver_warp.py:725-741, and the jelly / water branch of the step):
+// the constitutive half of compute_stress_from_F_trial (mpm_utils.py:495-526), symmetrised.  Material ids
+// (mpm_solver_warp.py:10-18): 0 jelly, 1 metal, 2 sand, 3 visplas, 5 snow, 6 "stationary" -- which the reference treats as
+// the water EOS with `bulk` (0 in every shipped flow => tau = 0); any other id gives tau = 0.
 PX_HD Mat3 kirchhoff_stress(int material, const Mat3& F, float mu, float lam, float bulk) {
     const float J = mat_det(F);
     Mat3 T;
@@ -440,21 +595,31 @@ PX_HD Mat3 kirchhoff_stress(int material, const Mat3& F, float mu, float lam, fl
         T.m[1] = T.m[3] = two_mu * P.xy; T.m[2] = T.m[6] = two_mu * P.xz; T.m[5] = T.m[7] = two_mu * P.yz;
         return T;   // symmetric by construction
     } else if (material == 6) {
-        T = stress_water(J, bulk);
+        return stress_water(J, bulk);   // isotropic
     } else if (material == 0 && polar_rotation(F, Rp)) {
-        // fixed-corotated jelly: only the rotation is needed -- Newton polar instead of the full SVD
+        // fixed-corotated jelly: only the rotation is needed -- Newton polar instead of the decomposition
         Mat3 D;
         for (int i = 0; i < 9; ++i) D.m[i] = 2.0f * mu * (F.m[i] - Rp.m[i]);
         T = mat_mul_bt(D, F);
         const float iso = lam * J * (J - 1.0f);
         T.m[0] += iso; T.m[4] += iso; T.m[8] += iso;
-    } else if (material == 0 || material == 5 || material == 1 || material == 2 || material == 3) {
-        Mat3 U, V;
-        float sg[3];
-        svd3(F, U, sg, V);
-        if (material == 0 || material == 5) T = stress_fcr(F, U, V, J, mu, lam);
-        else if (material == 2) T = stress_dp(F, U, V, sg, mu, lam);
-        else T = stress_stvk(F, U, V, sg, mu, lam);
+    } else if (material == 0) {
+        return stress_fcr_svd(F, J, mu, lam);
+    } else if (is_svd_material(material)) {
+        // the stress of an F that is already elastic: the stress half of return_map_principal with nothing to return
+        Mat3 U;
+        float sg[3], t[3];
+        left_stretch(F, J, U, sg);
+        if (material == 5) {
+            const float iso = lam * J * (J - 1.0f);
+            for (int d = 0; d < 3; ++d) t[d] = 2.0f * mu * (sg[d] - 1.0f) * sg[d] + iso;
+        } else {
+            float l[3];
+            for (int d = 0; d < 3; ++d) l[d] = (material == 2) ? px_log(sg[d]) : px_log(fmaxf(sg[d], 0.01f));
+            const float ltr = l[0] + l[1] + l[2];
+            for (int d = 0; d < 3; ++d) t[d] = (2.0f * mu * l[d] + lam * ltr) * ((material == 2) ? 1.0f : sg[d]);
+        }
+        return mat_udut(U, t);
     }
     Mat3 tau;
     for (int i = 0; i < 3; ++i)
@@ -466,12 +631,20 @@ PX_HD Mat3 kirchhoff_stress(int material, const Mat3& F, float mu, float lam, fl
 // mu/lam/ys are the particle's mutable model entries (snow damage and hardening write them).
 PX_HD void return_map_and_stress(int material, const Mat3& Ft, float& mu, float& lam, float bulk, float& ys,
                                  const MaterialScalars& ms, float dt, Mat3& F, Mat3& tau) {
-    if (material == 1) F = rm_von_mises(Ft, ys, mu, lam, ms, false);
-    else if (material == 2) F = rm_sand(Ft, mu, lam, ms);
-    else if (material == 3) F = rm_visco(Ft, ys, mu, ms, dt);
-    else if (material == 5) F = rm_von_mises(Ft, ys, mu, lam, ms, true);
-    else F = Ft;
-    tau = kirchhoff_stress(material, F, mu, lam, bulk);
+    F = Ft;
+    if (is_svd_material(material)) {
+        Mat3 U;
+        float so[3], sn[3], rm1[3], t[3];
+        const float J = mat_det(Ft);
+        left_stretch(Ft, J, U, so);
+        if (return_map_principal(material, so, J, mu, lam, ys, ms, dt, sn, rm1, t)) {
+            const Mat3 GF = mat_mul(mat_udut(U, rm1), Ft);
+            for (int i = 0; i < 9; ++i) F.m[i] = Ft.m[i] + GF.m[i];
+        }
+        tau = mat_udut(U, t);
+    } else {
+        tau = kirchhoff_stress(material, Ft, mu, lam, bulk);
+    }
 }
 
 // ---------------------------------------------------------------- B-spline stencil

@@ -16,6 +16,7 @@ def load():
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", SRC, "-o", LIB])
     lib = C.CDLL(LIB)
     lib.hh_svd3.argtypes = [C.c_int] + [C.c_void_p] * 4
+    lib.hh_left_stretch.argtypes = [C.c_int] + [C.c_void_p] * 4
     lib.hh_stress.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 6 + [C.c_void_p] * 2
     lib.hh_polar.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hh_stencil.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -13,6 +13,15 @@ void hh_svd3(int n, const float* A, float* U, float* S, float* V) {
         for (int i = 0; i < 3; ++i) S[3 * p + i] = s[i];
     }
 }
+void hh_left_stretch(int n, const float* A, float* U, float* S, int* sweeps) {
+    for (int p = 0; p < n; ++p) {
+        Mat3 F, u; float s[3];
+        for (int i = 0; i < 9; ++i) F.m[i] = A[9 * p + i];
+        left_stretch(F, mat_det(F), u, s, &sweeps[p]);
+        for (int i = 0; i < 9; ++i) U[9 * p + i] = u.m[i];
+        for (int i = 0; i < 3; ++i) S[3 * p + i] = s[i];
+    }
+}
 void hh_stress(int n, const int* material, const float* Ft, float* mu, float* lam, const float* bulk, float* ys,
                float alpha, float hardening, float xi, float softening, float plastic_viscosity, float dt,
                float* Fout, float* tau) {
