@@ -27,7 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from pixie_amd import distributed as pd  # noqa: E402
-from pixie_amd.synthetic import apply_scene, feature_grid, mpm_ball_scene  # noqa: E402
+from pixie_amd.synthetic import PLASTIC_CONFIGS, apply_scene, feature_grid, mpm_ball_scene, mpm_plastic_scene, start_plastic  # noqa: E402
 from pixie_amd.unet_plan import UNetConfig, conv_flops, synthetic_state_dict  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -111,6 +111,8 @@ def parse():
     ap.add_argument("--no-shipped-shape", action="store_true", help="skip the 64^3 x 768 fp16-grid sub-record")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32-MFMA sub-record of the same U-Net step")
     ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
+    ap.add_argument("--no-mpm-plastic", action="store_true", help="skip the sand / snow / metal / mixed-material 1M-particle legs")
+    ap.add_argument("--mpm-plastic-substeps", type=int, default=400)
     ap.add_argument("--no-unet-256", action="store_true", help="skip the 256^3 x 128 U-Net sub-record (BASELINE configs[4]'s per-GPU grid)")
     ap.add_argument("--dual-stream-diagnostic", action="store_true",
                     help="also time one scene's launches with the two networks on two HIP streams (roofline.avg_launch_ms_dual_stream)")
@@ -413,12 +415,28 @@ def load_traffic():
         return {}
 
 
+PLASTIC_LEGS = ("sand", "snow", "metal", "mixed")
+
+
+def load_counters():
+    """SQ counters and rocprofv3 kernel durations of the MPM block kernel per scene from the committed profile passes
+    (profiles/mpm_counters.json, written by scripts/mpm_counters.py from separate `rocprofv3 --pmc` / `--kernel-trace --stats`
+    runs of scripts/mpm_bench.py): counters cannot be collected from inside this process."""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "mpm_counters.json")))
+    except Exception:
+        return {}
+
+
 def _mpm_solver(sc, scatter_bits=None, wide=None):
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
-    apply_scene(s, sc)
+    if "F0" in sc:    # a plastic scene: the reference's config + a perturbed start, so that the return mappings work from substep 1
+        start_plastic(s, sc, lambda f, a: s.set_field(f, a.reshape(a.shape[0], -1)))
+    else:
+        apply_scene(s, sc)
     if scatter_bits:
         s._set_scalar("scatter_bits", scatter_bits)
     if wide is not None:
@@ -426,11 +444,17 @@ def _mpm_solver(sc, scatter_bits=None, wide=None):
     return s
 
 
-def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatter_bits=None, loop_api=False, v0_rms=None):
+def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatter_bits=None, loop_api=False, v0_rms=None, scenario=None):
     """One scene per GPU: `substeps` substeps through run() (the fused step loop), timed with barriers; a short separate pass
     with HIP events around every launch for the kernel roofline; optionally the reference driver's own loop
-    (gs_simulation.py:633-634: one p2g2p() call per substep, then an export), which the shim defers into the same run()."""
-    sc = mpm_ball_scene(particles, seed=rank, n_grid=n_grid)
+    (gs_simulation.py:633-634: one p2g2p() call per substep, then an export), which the shim defers into the same run().
+    `scenario`: None = the jelly ball of BASELINE configs[2]/[4]; "sand" / "snow" / "metal" / "mixed" = the reference's own plastic
+    configuration of that name (pixie_amd.synthetic.PLASTIC_CONFIGS: its n_grid and substep; `n_grid` is ignored)."""
+    if scenario:
+        sc = mpm_plastic_scene(scenario, particles, seed=rank)
+        n_grid = sc["n_grid"]
+    else:
+        sc = mpm_ball_scene(particles, seed=rank, n_grid=n_grid)
     s = _mpm_solver(sc, scatter_bits)
     if v0_rms:   # a scene in motion (strains of a few per cent): the block kernel's polar iteration then takes 2-3 steps per particle, not 1
         s.import_particle_v_from_torch(v0_rms * torch.randn((particles, 3), generator=torch.Generator().manual_seed(1 + rank)))
@@ -476,8 +500,10 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatt
     finite = bool(torch.isfinite(s.get_field("x")).all())
     ps = world * particles * substeps / dt
     out = {"value": ps, "unit": "particle-steps/s", "substeps": substeps, "us_per_substep": 1e6 * dt / substeps,
-           "config": {"workload": f"{particles} particles, n_grid {n_grid}, grid_lim 2, dt 1e-4, jelly ball, tree scenario "
-                                  "(impulse + ground slab), 1 scene per GPU", "scatter_bits": bits},
+           "config": {"workload": (f"{particles} particles, n_grid {n_grid}, grid_lim 2, dt {sc['dt']:g}, " +
+                                   (f"the reference's custom_{scenario}_config.json (ball, perturbed F and v)" if scenario and scenario != "mixed" else
+                                    "material ids 0/1/2/5 drawn per particle (ball, perturbed F and v)" if scenario else "jelly ball, tree scenario (impulse + ground slab)")
+                                   + ", 1 scene per GPU"), "scatter_bits": bits},
            "algorithmic_GBps": alg_bytes * substeps / dt / 1e9,
            # SURVEY 8d lets a sparse-grid implementation count touched cells "but must report which it used": both are reported;
            # `frac_touched_cells` is the honest one for this implementation (its kernels never move the inactive cells' bytes)
@@ -832,6 +858,14 @@ def compact_line(d, detail_path=None):
         line["mpm_1m_2_scenes_us_per_scene_substep"] = _r(two["us_per_scene_substep"])
         line["mpm_1m_2_scenes_frac_touched"] = _r(two["frac_touched_cells"])
         line["mpm_1m_2_scenes_frac_dense"] = _r(two["frac_dense_grid"])
+    for name, mp in ((d.get("mpm_1m") or {}).get("plastic") or {}).items():
+        ctr = mp.get("counters") or {}
+        line[f"mpm_1m_{name}"] = {"us_per_substep": _r(mp["us_per_substep"]), "frac_dense": _r(mp["frac_dense_grid"]), "frac_touched": _r(mp["frac_touched_cells"]),
+                                  "block_kernel_us": mp["block_kernel_us"], "vs_jelly": _r(mp["vs_jelly_1m_substep"], 3),
+                                  "valu_per_wave": ctr.get("valu_per_wave"), "block_kernel_us_rocprofv3": ctr.get("block_kernel_us")}
+    jc = (d.get("mpm_1m") or {}).get("counters") or {}
+    if jc:
+        line["mpm_1m_valu_per_wave"], line["mpm_1m_block_kernel_us_rocprofv3"] = jc.get("valu_per_wave"), jc.get("block_kernel_us")
     mv = (d.get("mpm_1m") or {}).get("in_motion")
     if mv:
         line["mpm_1m_in_motion_us_per_substep"] = _r(mv["us_per_substep"])
@@ -919,6 +953,20 @@ def main():
                                          "frac_touched_cells": m_large["substep_bytes_touched"] / (per_scene_us * 1e-6) / 1e9 / PEAK_HBM_GBPS,
                                          "config": two["config"], "timing": two["timing"],
                                          "repetitions_us_per_scene_substep": [round(r / 2.0, 2) for r in two["repetitions_us_per_substep"]]}
+            if m_large is not None and not args.no_mpm_plastic:
+                # SURVEY 8f-4 "plastic materials at scale": the reference's own sand / snow / metal configurations and a mixed-material
+                # scene at the 1 M size (the constitutive branch is the only thing that differs from the jelly leg above)
+                m_plastic = {}
+                for name in PLASTIC_LEGS:
+                    mp = bench_mpm(args, rank, world, device, 1_000_000, 0, args.mpm_plastic_substeps, "1m_" + name, scenario=name)
+                    m_plastic[name] = {k: mp[k] for k in ("value", "substeps", "us_per_substep", "frac_dense_grid", "frac_touched_cells", "active_blocks",
+                                                          "finite", "out_of_bounds", "rebins", "config")}
+                    m_plastic[name]["block_kernel_us"] = round(1e3 * mp["roofline"]["avg_launch_ms"], 2)
+                    m_plastic[name]["grid_kernel_us"] = round(1e3 * mp["roofline"]["grid_kernel_ms"], 2)
+                    m_plastic[name]["vs_jelly_1m_substep"] = mp["us_per_substep"] / m_large["us_per_substep"]
+                    m_plastic[name]["counters"] = load_counters().get("1m_" + name)
+                m_large["plastic"] = m_plastic
+                m_large["counters"] = load_counters().get("1m_jelly")
             m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
             six = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 6)
             m_multi["six_scenes"] = {k: six[k] for k in ("value", "unit", "scenes", "us_per_substep_per_scene", "finite")}
@@ -945,8 +993,15 @@ def main():
                 json.dump(detail, f, indent=1)
         except OSError:
             path = None
-        text = json.dumps(compact_line(detail, path))
-        assert len(text) < 6144 or dry, f"bench line grew to {len(text)} bytes (the driver's record keeps ~6 KB)"
+        line = compact_line(detail, path)
+        text = json.dumps(line)
+        # the driver's record keeps ~6 KB of the line: drop optional keys (they stay in the detail file) rather than lose the run
+        for key in ("telemetry", "exact_f32", "mpm_cpu_baseline", "mpm_1m_cpu_baseline", "mpm_1m_kernel", "mpm_kernel", "mpm_1m_mixed", "mpm_1m_snow"):
+            if len(text) < 6144:
+                break
+            if line.pop(key, None) is not None:
+                print(f"bench.py: line was {len(text)} bytes, dropped '{key}' (kept in {path})", file=sys.stderr)
+                text = json.dumps(line)
         print(text)
     if world > 1:
         torch.distributed.barrier()

@@ -1671,7 +1671,7 @@ void launch_block_p(const pixie_mpm* h, bool pack, dim3 grid, hipStream_t st, co
     else launch_block<G, P, OCC, BASE>(h, grid, st, sp, pms);
 }
 
-// the fused G2P + P2G launch in the variant the scene calls for (shared by launch_particle and the captured step graph)
+// the fused G2P + P2G launch in the variant the scene calls for
 void launch_fused_block(const pixie_mpm* h, hipStream_t st, const StepParams& sp, const PModSet& pms) {
     const dim3 grid((unsigned)std::max(h->n_items, 1));
     const bool pack = h->scatter_bits == 32;
@@ -1680,23 +1680,20 @@ void launch_fused_block(const pixie_mpm* h, hipStream_t st, const StepParams& sp
     const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 3 * h->n_cus);
     if (h->trace) launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms);
     else if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
-    else if (h->occupancy >= 6) launch_block_p<true, true, 6, 0>(h, pack, grid, st, sp, pms);
+    else if (h->occupancy >= 6 && !pack) launch_block<true, true, 6, 0>(h, grid, st, sp, pms);   // six waves per SIMD: the exact scatter only (the one measured and tested)
     else launch_block_p<true, true, 5, 0>(h, pack, grid, st, sp, pms);
 }
 
 // particle modifiers whose window contains `time` (float compare, as the kernels do), impulses first (mpm_solver_warp.py:529-547)
-std::vector<PModDev> active_pmods(const pixie_mpm* h, float time, unsigned long long* mask = nullptr) {
+std::vector<PModDev> active_pmods(const pixie_mpm* h, float time) {
     std::vector<PModDev> ordered;
-    unsigned long long m = 0;
     for (int pass = 0; pass < 2; ++pass)
         for (size_t k = 0; k < h->pmods.size(); ++k) {
             const PModDev& pm = h->pmods[k];
             if ((pm.type == PIXIE_PM_IMPULSE) != (pass == 0)) continue;
             if (!(time >= pm.start && time < pm.end)) continue;
             ordered.push_back(pm);
-            m |= 1ull << (k & 63);
         }
-    if (mask) *mask = m;
     return ordered;
 }
 
@@ -1924,6 +1921,7 @@ int pixie_mpm_regrid(pixie_mpm* h, int n_grid, double grid_lim, void* stream) {
     if (alloc_grid(h, n_grid, grid_lim)) return 1;
     bind_rows(h);
     hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S.selection, h->S.n);
+    h->mass_range_dirty = true;   // re-admitted particles count towards the mass contrast again
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1945,6 +1943,7 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     if (nm == "x") {   // positions replaced: binning stale, frozen particles get another chance
         h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval;
         hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S.selection, n);
+        h->mass_range_dirty = true;   // re-admitted particles count towards the mass contrast again
     }
     if (fi.is_int)
         hipLaunchKernelGGL(aos_to_soa_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)d_src, (int*)fi.ptr, n, fi.k, h->S.perm);

@@ -184,6 +184,14 @@ class MPM_Simulator_WARP:
             queued = getattr(self, "_pending_stream", None)     # the stream the substeps were queued under (an integer handle)
             self._pending_stream = None
             check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, self._stream if queued is None else C.c_void_p(queued)), "pixie_mpm_step")
+            # The substeps reach their stream only NOW.  A caller synchronised for the reference's eager semantics
+            # (`current.wait_stream(side)` right after its p2g2p() loop) waited on a stream that was still empty, so whatever
+            # observes or continues the solver on the CURRENT stream has to be ordered after them here.
+            if queued is not None and queued != self._raw_stream():
+                qs = torch.cuda.ExternalStream(queued, device=self._dev_index) if queued else torch.cuda.default_stream(self._dev_index)
+                ev = torch.cuda.Event()
+                ev.record(qs)
+                torch.cuda.current_stream(self._dev_index).wait_event(ev)
             self._warn_if_particles_lost()
 
     def _get_scalar(self, key):

@@ -141,7 +141,8 @@ def smooth_constrained(density: torch.Tensor, max_iters: int = 500, rel_tol: flo
         x = torch.minimum(torch.maximum(x, lower), upper)
         if (i + 1) % check_each == 0:
             energy_before, energy_now = energy_now, float(apply_q(x)[1]) / 2
-            if (energy_before - energy_now) / energy_before < cum_rel_tol:
+            # zero energy: already flat (the NumPy form of this loop divides 0 by 0 into NaN and keeps iterating to no effect)
+            if energy_before <= 0.0 or (energy_before - energy_now) / energy_before < cum_rel_tol:
                 break
     return torch.where(band, x, u0)
 

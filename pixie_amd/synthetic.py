@@ -69,6 +69,55 @@ def mpm_ball_scene(n_particles: int = 100_000, seed: int = 0, n_grid: int = 50, 
     return scene
 
 
+# The reference's own plastic configurations (PhysGaussian/config/objaverse/custom_{sand,snow,metal}_config.json: material
+# parameters, n_grid, substep_dt, gravity, damping, boundary conditions as shipped).
+_BBOX = dict(type="bounding_box")
+PLASTIC_CONFIGS = {
+    "sand": dict(n_grid=200, dt=2e-5, params=dict(material="sand", E=5e7, nu=0.3, density=2000.0, g=[0.0, 0.0, -9.8], friction_angle=30.0),
+                 bcs=[_BBOX, dict(type="surface_collider", point=[1.0, 1.0, 0.48], normal=[0.0, 0.0, 1.0], surface="sticky", friction=0.0,
+                                  start_time=0.0, end_time=1e3)]),
+    "snow": dict(n_grid=120, dt=1e-5, params=dict(material="snow", E=1e5, yield_stress=5e2, nu=0.2, softening=0.5, grid_v_damping_scale=0.9999,
+                                                  density=2700.0, g=[0.0, 0.0, -9.8]), bcs=[_BBOX]),
+    "metal": dict(n_grid=120, dt=1e-5, params=dict(material="metal", E=1e8, yield_stress=1e7, nu=0.3, hardening=1, xi=0.1,
+                                                   grid_v_damping_scale=0.9999, density=2700.0, g=[0.0, 0.0, -9.8]), bcs=[_BBOX]),
+    # what material_mode=neural produces: ONE set of solver scalars (the scene's config) and a per-particle material id from
+    # the predicted field (PhysGaussian/material_field.py:343-363).  Ids 0 / 1 / 2 / 5 drawn per particle -- every wave of the
+    # fused kernel then holds all four constitutive branches (the worst case for divergence; a real field is piecewise constant).
+    "mixed": dict(n_grid=120, dt=1e-5, params=dict(material="jelly", E=2e6, yield_stress=2e4, nu=0.3, hardening=1, xi=0.1, softening=0.1,
+                                                   friction_angle=30.0, grid_v_damping_scale=0.9999, density=1500.0, g=[0.0, 0.0, -9.8]), bcs=[_BBOX]),
+}
+
+
+def mpm_plastic_scene(name: str, n_particles: int = 100_000, seed: int = 0):
+    """The ball of BASELINE config 3 / 5 under one of PLASTIC_CONFIGS.  A ball released at rest stays rigid (F = I, no stress)
+    until it reaches a wall, thousands of substeps away, so the initial state is perturbed to put the return mappings to work from
+    the first substep: F_trial = I + 0.02 N(0,1) per entry (0.15 for metal, whose yield strain sigma_y / 2 mu is 0.13) and
+    v = (0.3, -0.2, -1.0) + 0.2 N(0,1) m/s -- scene["F0"], scene["v0"], applied by start_plastic().  (n = 100 000, seed 0 is
+    the scene of tests/golden/mpm_plastic_*.npz.)"""
+    cfg = PLASTIC_CONFIGS[name]
+    sc = mpm_ball_scene(n_particles, seed=seed, n_grid=cfg["n_grid"], dt=cfg["dt"], scenario="ball")
+    sc["params"] = dict(cfg["params"]); sc["bcs"] = list(cfg["bcs"]); sc["fix_ground"] = None
+    rng = np.random.default_rng(100 + len(name))
+    amp = 0.15 if name == "metal" else 0.02
+    sc["F0"] = (np.eye(3) + amp * rng.normal(size=(n_particles, 3, 3))).astype(np.float32)
+    sc["v0"] = (np.array([0.3, -0.2, -1.0]) + 0.2 * rng.normal(size=(n_particles, 3))).astype(np.float32)
+    p = cfg["params"]
+    sc["E"] = np.full(n_particles, p["E"], np.float32); sc["nu"] = np.full(n_particles, p["nu"], np.float32)
+    sc["density"] = np.full(n_particles, p["density"], np.float32)
+    if name == "mixed":
+        sc["material"] = np.array([0, 1, 2, 5], np.int32)[rng.integers(0, 4, n_particles)]
+        sc["per_particle"] = True
+    else:
+        sc["per_particle"] = False
+    return sc
+
+
+def start_plastic(solver, sc, set_field):
+    """apply_scene + the perturbed initial state; set_field(name, array) writes a particle field of `solver`."""
+    apply_scene(solver, sc, per_particle=sc.get("per_particle", False))
+    set_field("F_trial", sc["F0"]); set_field("v", sc["v0"])
+
+
 def ground_slab(positions: np.ndarray, delta_z: float = 0.02, buffer_xy: float = 0.5):
     """Cuboid of fix_to_ground (PhysGaussian/material_field.py:485-550), min_z_percentile=1."""
     min_xy = positions[:, :2].min(axis=0)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """MPM-only timing on the GPU box: us/substep, fused-kernel / grid-kernel durations (HIP events on the launch
-stream), work items, slow-path particles.  Usage: python scripts/mpm_bench.py N NGRID [SUBSTEPS] [RESORT]"""
+stream), work items, slow-path particles.  Usage: python scripts/mpm_bench.py N NGRID [SUBSTEPS] [RESORT]
+PIXIE_MPM_SCENARIO = tree (default) | ball | sand | snow | metal | mixed (the last four: pixie_amd.synthetic.PLASTIC_CONFIGS; NGRID 0 = the config's)"""
 import os
 import sys
 import time
@@ -9,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pixie_amd.mpm_solver import MPM_Simulator_WARP  # noqa: E402
-from pixie_amd.synthetic import apply_scene, mpm_ball_scene  # noqa: E402
+from pixie_amd.synthetic import PLASTIC_CONFIGS, apply_scene, mpm_ball_scene, mpm_plastic_scene, start_plastic  # noqa: E402
 
 
 def main():
@@ -17,11 +18,21 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     resort = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     scenario = os.environ.get("PIXIE_MPM_SCENARIO", "tree")
-    sc = mpm_ball_scene(n, seed=0, n_grid=ng, scenario=scenario, dt=float(os.environ.get("PIXIE_MPM_DT", "1e-4")))
+    plastic = scenario in PLASTIC_CONFIGS   # sand / snow / metal / mixed: the reference's own config (NGRID 0 = its n_grid), perturbed start
+    if plastic:
+        sc = mpm_plastic_scene(scenario, n, seed=0)
+        if ng > 0:
+            sc["n_grid"] = ng
+        ng = sc["n_grid"]
+    else:
+        sc = mpm_ball_scene(n, seed=0, n_grid=ng, scenario=scenario, dt=float(os.environ.get("PIXIE_MPM_DT", "1e-4")))
     s = MPM_Simulator_WARP(10)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
-    apply_scene(s, sc)
+    if plastic:
+        start_plastic(s, sc, lambda f, a: s.set_field(f, a.reshape(n, -1)))
+    else:
+        apply_scene(s, sc)
     if resort > 0:
         s._set_scalar("resort_interval", resort)
     if os.environ.get("PIXIE_MPM_TRACE"):

@@ -24,34 +24,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle.mpm_oracle import OracleMPM  # noqa: E402
 from pixie_amd.synthetic import apply_scene, mpm_ball_scene  # noqa: E402
 
+from pixie_amd.synthetic import PLASTIC_CONFIGS, mpm_plastic_scene, start_plastic  # noqa: E402
+
 N, SEED, STRIDE = 100_000, 0, 16
 CHECKPOINTS = (50, 200)
-BBOX = dict(type="bounding_box")
-CONFIGS = {   # custom_{sand,snow,metal}_config.json
-    "sand": dict(n_grid=200, dt=2e-5, params=dict(material="sand", E=5e7, nu=0.3, density=2000.0, g=[0.0, 0.0, -9.8], friction_angle=30.0),
-                 bcs=[BBOX, dict(type="surface_collider", point=[1.0, 1.0, 0.48], normal=[0.0, 0.0, 1.0], surface="sticky", friction=0.0,
-                                 start_time=0.0, end_time=1e3)]),
-    "snow": dict(n_grid=120, dt=1e-5, params=dict(material="snow", E=1e5, yield_stress=5e2, nu=0.2, softening=0.5, grid_v_damping_scale=0.9999,
-                                                  density=2700.0, g=[0.0, 0.0, -9.8]), bcs=[BBOX]),
-    "metal": dict(n_grid=120, dt=1e-5, params=dict(material="metal", E=1e8, yield_stress=1e7, nu=0.3, hardening=1, xi=0.1,
-                                                   grid_v_damping_scale=0.9999, density=2700.0, g=[0.0, 0.0, -9.8]), bcs=[BBOX]),
-}
+CONFIGS = {k: PLASTIC_CONFIGS[k] for k in ("sand", "snow", "metal")}
 
 
 def plastic_scene(name):
-    cfg = CONFIGS[name]
-    sc = mpm_ball_scene(N, seed=SEED, n_grid=cfg["n_grid"], dt=cfg["dt"], scenario="ball")
-    sc["params"] = dict(cfg["params"]); sc["bcs"] = list(cfg["bcs"]); sc["fix_ground"] = None
-    rng = np.random.default_rng(100 + len(name))
-    amp = 0.15 if name == "metal" else 0.02      # metal yields at a log-strain of sigma_y / 2 mu = 0.13
-    sc["F0"] = (np.eye(3) + amp * rng.normal(size=(N, 3, 3))).astype(np.float32)
-    sc["v0"] = (np.array([0.3, -0.2, -1.0]) + 0.2 * rng.normal(size=(N, 3))).astype(np.float32)
-    return sc
+    return mpm_plastic_scene(name, N, SEED)
 
 
 def start(solver, sc, set_field):
-    apply_scene(solver, sc, per_particle=False)
-    set_field("F_trial", sc["F0"]); set_field("v", sc["v0"])
+    start_plastic(solver, sc, set_field)
 
 
 def main():

@@ -332,6 +332,30 @@ def test_deferred_substeps_keep_the_stream_they_were_queued_on(hip_device):
     assert np.array_equal(get(a, "x"), get(b, "x")) and np.array_equal(get(a, "F_trial"), get(b, "F_trial"))
 
 
+def test_deferred_substeps_order_the_observing_stream_after_them(hip_device):
+    """the caller synchronises as it would for the reference's eager kernels -- wait_stream(side) right after the
+    p2g2p() loop, BEFORE anything flushes the queue -- so that wait sees an empty stream.  The flush (here: the next batch on the
+    default stream, then an export) must itself order the current stream after the substeps it puts on `side`; a slow kernel is
+    put in front of them on `side` so that a missing dependency shows as a race."""
+    sc = mpm_ball_scene(200_000, seed=9, n_grid=64)
+    a, b = make_hip(sc), make_hip(sc)
+    side = torch.cuda.Stream(hip_device)
+    side.wait_stream(torch.cuda.current_stream())
+    ballast = torch.randn((4096, 4096), device=hip_device)
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            ballast = ballast @ ballast * 1e-3         # keeps `side` busy when the substeps arrive on it
+        for i in range(5):
+            a.p2g2p(i, sc["dt"])
+    torch.cuda.current_stream().wait_stream(side)       # too early to see the substeps: they are still queued in the shim
+    for i in range(5, 9):
+        a.p2g2p(i, sc["dt"])                            # first call flushes the five onto `side`; these four run on the current stream
+    xa = a.export_particle_x_to_torch().clone()
+    b.run(sc["dt"], 9)
+    assert torch.equal(xa, b.export_particle_x_to_torch())
+    assert np.array_equal(get(a, "F_trial"), get(b, "F_trial"))
+
+
 def test_mass_contrast_selects_the_exact_scatter(hip_device):
     """the packed scatter's quantum is 2^-30 of the SUM of a work item's bounds, so nodes fed only by particles much
     lighter than their tile-mates are quantised at visible weights.  A scene whose upper half is 1e4 times lighter than its
