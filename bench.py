@@ -428,9 +428,9 @@ def load_counters():
         return {}
 
 
-def _mpm_solver(sc, scatter_bits=None, wide=None):
+def _mpm_solver(sc, scatter_bits=None, wide=None, diag=False):
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
-    s = MPM_Simulator_WARP(10)
+    s = MPM_Simulator_WARP(10, diag=diag)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
     if "F0" in sc:    # a plastic scene: the reference's config + a perturbed start, so that the return mappings work from substep 1
@@ -478,12 +478,19 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatt
                 "host_us_per_p2g2p_call": 1e6 * t_host / substeps, "vs_run": dl / dt,
                 "what": f"for step in range({substeps}): solver.p2g2p(step, dt); then export_particle_x_to_torch() -- the calls are queued "
                         "and run as ONE fused run() at the export (pixie_amd/mpm_solver.py)"}
-    # separate short pass with per-launch HIP events on the launch stream for the roofline of the fused block kernel
-    s.set_profile(True)
-    s.run(sc["dt"], 200)
+    # separate short pass with per-launch HIP events on the launch stream for the roofline of the fused block kernel: the event
+    # bracketing is a diagnostic of the PIXIE_DIAG build (libpixie_hip_diag.so: the same sources and kernels + the diagnostic
+    # entry points), so this pass runs the same scene on a second solver from that library; the timed region above is the product's
+    sd = _mpm_solver(sc, scatter_bits, diag=True)
+    if v0_rms:
+        sd.import_particle_v_from_torch(v0_rms * torch.randn((particles, 3), generator=torch.Generator().manual_seed(1 + rank)))
+    sd.run(sc["dt"], 300 if v0_rms else 50)
+    sd.set_profile(True)
+    sd.run(sc["dt"], 200)
     torch.cuda.synchronize()
-    p_ms, g_ms, n_launch = s.kernel_times()
-    s.set_profile(False)
+    p_ms, g_ms, n_launch = sd.kernel_times()
+    sd.set_profile(False)
+    del sd
     alg_bytes = 212.0 * particles + 44.0 * n_grid ** 3  # SURVEY.md section 8d (fused minimum, DENSE grid term)
     active_blocks = int(s._get_scalar("n_active_blocks"))
     touched_bytes = 212.0 * particles + 44.0 * 64 * active_blocks   # same, with the cells of the ACTIVE 4^3 blocks only

@@ -111,9 +111,6 @@ int pixie_mpm_add_particle_modifier(pixie_mpm* h, const pixie_pmod_desc* pm, voi
 
 /* p2g2p (mpm_solver_warp.py:514-637), n_substeps times with the same dt; advances h->time. */
 int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream);
-/* One phase of a substep, for per-kernel parity tests: 0 = pre-P2G modifiers + stress + P2G,
- * 1 = grid update + damping + BCs (+ host `modify`), 2 = G2P.  Does not advance time. */
-int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream);
 
 /* compute_cov_from_F (mpm_utils.py:529-553) and compute_R_from_F (:556-580) as used by
  * export_particle_cov_to_torch / export_particle_R_to_torch (mpm_solver_warp.py:702-741). */
@@ -133,9 +130,6 @@ int pixie_mpm_export_frame(pixie_mpm* h, int n_out, const double shift[3], doubl
  * `stream`.  pixie_mpm_get_scalar("lost_particles_seen") returns the same count as of the last re-binning without
  * synchronising (the Python shim warns when it becomes non-zero). */
 int pixie_mpm_out_of_bounds(pixie_mpm* h, int64_t* count, void* stream);
-/* Average duration in ms of the fused particle kernel / grid kernel over the launches since the
- * last call, measured with HIP events on `stream` (enable with set_scalar "profile"=1). */
-int pixie_mpm_kernel_times(pixie_mpm* h, double* particle_ms, double* grid_ms, int64_t* n_launches);
 
 /* ======================================================================================
  * (A) 3D U-Net operators -- replace the torch ops under WG/models/module/diffusion_network.py
@@ -219,11 +213,6 @@ int pixie_conv3d_forward(const pixie_conv_desc* desc, void* stream);
 int64_t pixie_conv_stats_floats(const pixie_conv_desc* desc);
 int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* desc);
 int pixie_stats_finalize(const float* d_stats, const pixie_conv_desc* desc, double* d_sums, void* stream);
-/* Which kernel instantiation pixie_conv3d_forward picks for this descriptor: ksize*100 + MB*10 + NB of
- * conv3d_f16x3_kernel<ksize,MB,NB> (and its split-K factor in *slices), 9324 = conv3d_f16x3_c64_fullres_kernel (the <3,2,4>
- * code under its own symbol for the 64 -> 64 full-resolution 3^3 layers), 0 = the exact-fp32 kernel.  For profilers that
- * want to group per-launch timings by kernel name, as rocprofv3 does; no reference counterpart. */
-int pixie_conv_kernel_variant(const pixie_conv_desc* desc, int* slices);
 /* 1 if this descriptor's launch (its shape fields, d_w16 and d_workspace as they will be passed) can take a folded skip
  * convolution with skip_c0 + skip_c1 input channels; the skip pointers themselves need not be set yet. */
 int pixie_conv_skip_foldable(const pixie_conv_desc* desc);
@@ -396,6 +385,27 @@ int pixie_particle_volume(const float* d_pos, int n, int grid_n, double grid_dx,
 /* get_attr_from_closest (filling.py:383-403): d_nearest[i] = index of the original particle closest to new particle i
  * (first minimum in index order; brute force through LDS tiles). */
 int pixie_nearest_particle(const float* d_pos, int n, const float* d_new_pos, int n_new, int32_t* d_nearest, void* stream);
+
+/* ======================================================================================
+ * Diagnostic entry points -- NOT part of the drop-in ABI.  They exist only in the -DPIXIE_DIAG build of the same sources,
+ * libpixie_hip_diag.so, which the parity tests (per-phase comparison with the oracle) and the profilers (per-launch timings)
+ * load; the production library libpixie_hip.so exports none of them and carries no trace buffer.
+ * ====================================================================================== */
+#ifdef PIXIE_DIAG
+/* One phase of a substep, for per-kernel parity tests: 0 = pre-P2G modifiers + stress + P2G,
+ * 1 = grid update + damping + BCs (+ host `modify`), 2 = G2P.  Does not advance time. */
+int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream);
+
+/* Average duration in ms of the fused particle kernel / grid kernel over the launches since the
+ * last call, measured with HIP events on `stream` (enable with set_scalar "profile"=1). */
+int pixie_mpm_kernel_times(pixie_mpm* h, double* particle_ms, double* grid_ms, int64_t* n_launches);
+
+/* Which kernel instantiation pixie_conv3d_forward picks for this descriptor: ksize*100 + MB*10 + NB of
+ * conv3d_f16x3_kernel<ksize,MB,NB> (and its split-K factor in *slices), 9324 = conv3d_f16x3_c64_fullres_kernel (the <3,2,4>
+ * code under its own symbol for the 64 -> 64 full-resolution 3^3 layers), 0 = the exact-fp32 kernel.  For profilers that
+ * want to group per-launch timings by kernel name, as rocprofv3 does; no reference counterpart. */
+int pixie_conv_kernel_variant(const pixie_conv_desc* desc, int* slices);
+#endif /* PIXIE_DIAG */
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpixie_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "libpixie_hip_diag.so")   # the -DPIXIE_DIAG build of the same sources (tests, profilers)
 
 
 class PixieHipError(RuntimeError):
@@ -96,12 +97,10 @@ SIGNATURES = {
     "pixie_mpm_add_bc": (_I, [_VP, C.POINTER(BCDesc)]),
     "pixie_mpm_add_particle_modifier": (_I, [_VP, C.POINTER(PModDesc), _VP]),
     "pixie_mpm_step": (_I, [_VP, _D, _I, _VP]),
-    "pixie_mpm_phase": (_I, [_VP, _I, _D, _VP]),
     "pixie_mpm_export_cov": (_I, [_VP, _VP, _VP]),
     "pixie_mpm_export_R": (_I, [_VP, _VP, _VP]),
     "pixie_mpm_export_frame": (_I, [_VP, _I, _D3, _D, _D3, C.POINTER(C.c_double), _VP, _VP, _VP]),
     "pixie_mpm_out_of_bounds": (_I, [_VP, C.POINTER(_I64), _VP]),
-    "pixie_mpm_kernel_times": (_I, [_VP, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
     "pixie_conv_cout_padded": (_I, [_I]),
     "pixie_conv_pack_weights": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "pixie_conv_packed16_bytes": (_I64, [_I, _I, _I]),
@@ -109,7 +108,6 @@ SIGNATURES = {
     "pixie_conv3d_forward": (_I, [C.POINTER(ConvDesc), _VP]),
     "pixie_conv_stats_floats": (_I64, [C.POINTER(ConvDesc)]),
     "pixie_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
-    "pixie_conv_kernel_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
     "pixie_stats_finalize": (_I, [_VP, C.POINTER(ConvDesc), _VP, _VP]),
     "pixie_channel_stats": (_I, [_VP, _I, _I64, _VP, _VP, _VP]),
     "pixie_tensor_amax": (_I, [_VP, _I64, _VP, _VP]),
@@ -142,35 +140,44 @@ SIGNATURES = {
     "pixie_field_to_particles": (_I, [C.POINTER(FieldDesc), _VP, _I, _I, _D, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 
-_lib = None
+# entry points that exist only in the PIXIE_DIAG build (include/pixie_hip.h, last section)
+DIAG_SIGNATURES = {
+    "pixie_mpm_phase": (_I, [_VP, _I, _D, _VP]),
+    "pixie_mpm_kernel_times": (_I, [_VP, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
+    "pixie_conv_kernel_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+}
+
+_libs = {}
 
 
-def load():
-    """dlopen libpixie_hip.so and type every entry point; raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(diag: bool = False):
+    """dlopen libpixie_hip.so -- or, diag=True, libpixie_hip_diag.so, the same sources built with -DPIXIE_DIAG, which adds the
+    diagnostic entry points -- and type every entry point; raises if absent.  The two are independent libraries: a handle
+    belongs to the one that created it."""
+    if diag in _libs:
+        return _libs[diag]
+    path = DIAG_LIB_PATH if diag else LIB_PATH
+    if not os.path.exists(path):
         raise PixieHipError(
-            f"{LIB_PATH} not found: build it with `python -m pixie_amd.build` (hipcc, gfx950). "
+            f"{path} not found: build it with `python -m pixie_amd.build` (hipcc, gfx950). "
             "pixie_amd has no CPU fallback.")
     # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  The process must have ONE HIP runtime -- streams and
     # device pointers cross the C ABI in both directions -- so torch's copy has to be in the process before ours is resolved
     # (same SONAME: the loader then binds libpixie_hip.so to it).  Loaded the other way round, the system ROCm runtime and
     # torch's coexist and the first hipMalloc / launch on a torch stream fails.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    lib = C.CDLL(path)
+    for name, (res, args) in list(SIGNATURES.items()) + (list(DIAG_SIGNATURES.items()) if diag else []):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[diag] = lib
     return lib
 
 
-def check(rc: int, what: str = ""):
+def check(rc: int, what: str = "", lib=None):
     if rc != 0:
-        msg = load().pixie_last_error()
+        msg = (lib or load()).pixie_last_error()
         raise PixieHipError(f"{what}: {msg.decode() if msg else 'unknown error'}")
 
 

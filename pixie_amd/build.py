@@ -9,11 +9,13 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpixie_hip.so")
+LIB_DIAG = os.path.join(HERE, "libpixie_hip_diag.so")   # same sources + -DPIXIE_DIAG (tests, profilers)
 ARCH = "gfx950"
 SOURCES = ["common.hip", "mpm.hip", "unet_ops.hip", "conv3d_mfma.hip", "conv3d_f16x3.hip", "unet_exec.hip", "projector_fused.hip", "field_transfer.hip", "particle_filling.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
@@ -40,40 +42,60 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def _uses_diag(path: str) -> bool:
+    with open(path) as f:
+        return "PIXIE_DIAG" in f.read()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compiles csrc/*.hip into libpixie_hip.so (the product) and libpixie_hip_diag.so (the same sources with -DPIXIE_DIAG:
+    + pixie_mpm_phase / pixie_mpm_kernel_times / pixie_conv_kernel_variant and the kernel trace buffer, for tests and
+    profilers).  Only the sources that mention PIXIE_DIAG are compiled twice.  `force` (or PIXIE_FORCE_BUILD=1 in the
+    environment) recompiles everything and prints hipcc's wall time per file, so that a cold build is observable."""
+    force = force or os.environ.get("PIXIE_FORCE_BUILD", "") not in ("", "0")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "pixie_hip.h"))
     hipcc = _hipcc()
-    objs = []
+    objs = {False: [], True: []}
     procs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        objs.append(obj)
-        if not force and _newer(obj, [sp, os.path.abspath(__file__)] + headers):
-            continue
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for diag in ((False, True) if _uses_diag(sp) else (False,)):
+            obj = os.path.join(OBJ, src.replace(".hip", ".diag.o" if diag else ".o"))
+            objs[diag].append(obj)
+            if not force and _newer(obj, [sp, os.path.abspath(__file__)] + headers):
+                continue
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-DPIXIE_DIAG"] if diag else []) + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src + (" -DPIXIE_DIAG" if diag else ""), time.time(),
+                          subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        if not _uses_diag(sp):
+            objs[True].append(objs[False][-1])
     failed = False
-    for src, pr in procs:
+    for src, t0, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             failed = True
             sys.stderr.write(f"--- hipcc failed on {src} ---\n{out}\n")
-        elif verbose and out.strip():
-            print(out)
+        else:
+            if force or verbose:
+                print(f"hipcc {src}: done {time.time() - t0:.0f} s after launch (all files compile in parallel)", flush=True)
+            if verbose and out.strip():
+                print(out)
     if failed:
         raise RuntimeError("hipcc failed; see messages above")
-    if force or procs or not _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    for diag, lib in ((False, LIB), (True, LIB_DIAG)):
+        if force or procs or not _newer(lib, objs[diag]):
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs[diag]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB)} bytes) and {LIB_DIAG} ({os.path.getsize(LIB_DIAG)} bytes) from {len(procs)} compilations", flush=True)
     return LIB
 
 

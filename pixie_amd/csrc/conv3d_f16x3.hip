@@ -886,6 +886,7 @@ extern "C" int64_t pixie_conv_workspace_bytes(const pixie_conv_desc* d) {
 // which kernel instantiation pixie_conv3d_forward picks for this descriptor: variant = ksize * 100 + MB * 10 + NB of
 // conv3d_f16x3_kernel<ksize, MB, NB>, slices = its split-K factor; 0 = the exact-fp32 kernel.  (Lets a profiler group
 // its own per-launch timings the way rocprofv3 groups them: by kernel name.)
+#ifdef PIXIE_DIAG
 extern "C" int pixie_conv_kernel_variant(const pixie_conv_desc* d, int* slices_out) {
     if (slices_out) *slices_out = 1;
     if (!d || !d->d_w16 || !(d->stride == 1 || (d->stride == 2 && d->ksize == 3)) || (d->ksize != 1 && d->ksize != 3)) return 0;
@@ -898,6 +899,7 @@ extern "C" int pixie_conv_kernel_variant(const pixie_conv_desc* d, int* slices_o
         return 9324;   // conv3d_f16x3_c64_fullres_kernel: the <3,2,4> code under its own symbol
     return d->ksize * 100 + MB * 10 + NB;
 }
+#endif
 
 extern "C" int pixie_conv_skip_foldable(const pixie_conv_desc* d) {
     if (!d || !d->d_w16 || d->stride != 1 || d->upsample || (d->ksize != 1 && d->ksize != 3)) return 0;

@@ -589,9 +589,15 @@ __device__ __forceinline__ float wave_max_nonneg(float x) {
 
 // Phase trace (pixie_mpm_set_scalar "trace" 1; read back with pixie::mpm_trace_read, not part of the C ABI): per work item 8
 // 100 MHz timestamps -- start, tile staged, particles updated (G2P + stress), scales known, scatter done, tile published.
+// The trace buffer, the F_TRACE instantiation and every diagnostic entry point exist only in the -DPIXIE_DIAG build
+// (libpixie_hip_diag.so: tests and profilers); the production library carries none of it.
+#ifdef PIXIE_DIAG
 constexpr int kMpmTraceItems = 32768;
 __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
 #define PX_MPM_STAMP(i) do { if ((FL & F_TRACE) && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems) g_mpm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define PX_MPM_STAMP(i) do { } while (0)
+#endif
 
 // kernel variants (FL)
 constexpr int F_TRACE = 1;    // phase stamps + the ablation switches of StepParams.trace (timing studies only)
@@ -771,8 +777,10 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             }
         }
     PX_MPM_STAMP(5);
+#ifdef PIXIE_DIAG
     if (TRACE && (sp.trace & 1) && tid == 0 && blockIdx.x < (unsigned)kMpmTraceItems)   // where it ran: HW_ID | XCC_ID << 32
         g_mpm_trace[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+#endif
 }
 
 // ------------------------------------------------------------------ re-binning (counting sort by block)
@@ -1407,9 +1415,11 @@ __global__ void grid_export_kernel(const float4* __restrict__ g, float* __restri
     else { out[3 * i] = q.x; out[3 * i + 1] = q.y; out[3 * i + 2] = q.z; }
 }
 
+#ifdef PIXIE_DIAG
 int mpm_trace_read(unsigned long long* host, int n_words) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mpm_trace), (size_t)n_words * sizeof(unsigned long long));
 }
+#endif
 }  // namespace pixie
 
 // ====================================================================== host side
@@ -1678,8 +1688,10 @@ void launch_fused_block(const pixie_mpm* h, hipStream_t st, const StepParams& sp
     // Latency-optimised variant (no scheduling barriers, 130 VGPRs = three waves per SIMD = three 256-thread work items per CU at
     // once): up to that many the whole work list is resident in one round and a launch lasts one work item's latency.
     const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 3 * h->n_cus);
-    if (h->trace) launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms);
-    else if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
+#ifdef PIXIE_DIAG
+    if (h->trace) { launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms); return; }
+#endif
+    if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
     else if (h->occupancy >= 6 && !pack) launch_block<true, true, 6, 0>(h, grid, st, sp, pms);   // six waves per SIMD: the exact scatter only (the one measured and tested)
     else launch_block_p<true, true, 5, 0>(h, pack, grid, st, sp, pms);
 }
@@ -2027,7 +2039,11 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "gy") h->g[1] = (float)value;
     else if (k == "gz") h->g[2] = (float)value;
     else if (k == "time") h->time = value;
+#ifdef PIXIE_DIAG
     else if (k == "profile") h->profile = value != 0.0;
+#else
+    else if (k == "profile" || k == "trace") return set_error("pixie_mpm_set_scalar(%s): diagnostic switch, only in the PIXIE_DIAG build (libpixie_hip_diag.so)", key);
+#endif
     else if (k == "scatter_bits") {
         PX_REQUIRE(value == 64 || value == 32 || value == 0, "scatter_bits must be 0 (auto: by mass contrast), 64 (exact) or 32 (packed pairs)");
         h->scatter_bits_user = (int)value;
@@ -2036,7 +2052,9 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "grid_rb") { PX_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "grid_rb must be 0, 1, 2 or 4"); h->grid_rb = (int)value; }
     else if (k == "sparse_tiles") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "sparse_tiles must be -1 (auto), 0 or 1"); h->sparse = (int)value; h->needs_sort = true; }
     else if (k == "wide") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "wide must be -1 (auto), 0 or 1"); h->wide = (int)value; }
+#ifdef PIXIE_DIAG
     else if (k == "trace") h->trace = (int)value;
+#endif
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
@@ -2164,6 +2182,7 @@ int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream) {
     return 0;
 }
 
+#ifdef PIXIE_DIAG
 int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream) {
     PX_REQUIRE(h, "null handle");
     hipStream_t st = as_stream(stream);
@@ -2180,6 +2199,7 @@ int pixie_mpm_phase(pixie_mpm* h, int phase, double dt, void* stream) {
     }
     return set_error("pixie_mpm_phase: unknown phase %d", phase);
 }
+#endif
 
 int pixie_mpm_export_cov(pixie_mpm* h, float* d_cov, void* stream) {
     PX_REQUIRE(h && d_cov, "null argument");
@@ -2217,6 +2237,7 @@ int pixie_mpm_out_of_bounds(pixie_mpm* h, int64_t* count, void* stream) {
     return 0;
 }
 
+#ifdef PIXIE_DIAG
 int pixie_mpm_kernel_times(pixie_mpm* h, double* particle_ms, double* grid_ms, int64_t* n_launches) {
     PX_REQUIRE(h && particle_ms && grid_ms && n_launches, "null argument");
     double tp = 0.0, tg = 0.0;
@@ -2241,5 +2262,6 @@ int pixie_mpm_kernel_times(pixie_mpm* h, double* particle_ms, double* grid_ms, i
     h->ev_grid.clear();
     return 0;
 }
+#endif
 
 }  // extern "C"

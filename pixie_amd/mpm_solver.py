@@ -103,15 +103,21 @@ class _StructView:
 class MPM_Simulator_WARP:
     """mpm_solver_warp.py:47-1210"""
 
-    def __init__(self, n_particles, n_grid=100, grid_lim=1.0, device="cuda:0"):
+    def __init__(self, n_particles, n_grid=100, grid_lim=1.0, device="cuda:0", *, diag=False):
+        """`diag=True` (tests and profilers only, no reference counterpart): the handle lives in libpixie_hip_diag.so, the
+        -DPIXIE_DIAG build of the same sources, which adds phase() and kernel_times()."""
         self._h = None
+        self._diag = bool(diag)
         self.initialize(n_particles, n_grid, grid_lim, device=device)
         self.time_profile = {}
+
+    def _check(self, rc, what=""):
+        check(rc, what, lib=self._L)
 
     # ------------------------------------------------------------------ lifetime
     def initialize(self, n_particles, n_grid=100, grid_lim=1.0, device="cuda:0"):
         """:52-180"""
-        lib = _lib.load()
+        lib = self._L = _lib.load(diag=getattr(self, "_diag", False))
         if not torch.cuda.is_available():
             raise _lib.PixieHipError("MPM_Simulator_WARP needs a HIP device; pixie_amd has no CPU fallback")
         self._release()
@@ -125,7 +131,7 @@ class MPM_Simulator_WARP:
         self.n_grid = int(n_grid)
         self.grid_lim = float(grid_lim)
         h = C.c_void_p()
-        check(lib.pixie_mpm_create(C.byref(h), self.n_particles, self.n_grid, self.grid_lim), "pixie_mpm_create")
+        self._check(lib.pixie_mpm_create(C.byref(h), self.n_particles, self.n_grid, self.grid_lim), "pixie_mpm_create")
         self._h = h
         self._material = 0
         self._gravity = [0.0, 0.0, 0.0]
@@ -145,7 +151,7 @@ class MPM_Simulator_WARP:
     def _release(self):
         self._pending = 0   # queued substeps of a solver that is going away are dropped
         if getattr(self, "_h", None):
-            _lib.load().pixie_mpm_destroy(self._h)
+            self._L.pixie_mpm_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -174,7 +180,7 @@ class MPM_Simulator_WARP:
     @time.setter
     def time(self, value):
         self.flush()
-        check(_lib.load().pixie_mpm_set_scalar(self._h, b"time", float(value)), "set time")
+        self._check(self._L.pixie_mpm_set_scalar(self._h, b"time", float(value)), "set time")
 
     def flush(self):
         """Enqueue the substeps queued by p2g2p() on the current stream (asynchronous, like run())."""
@@ -183,7 +189,7 @@ class MPM_Simulator_WARP:
             self._pending = 0
             queued = getattr(self, "_pending_stream", None)     # the stream the substeps were queued under (an integer handle)
             self._pending_stream = None
-            check(_lib.load().pixie_mpm_step(self._h, self._pending_dt, n, self._stream if queued is None else C.c_void_p(queued)), "pixie_mpm_step")
+            self._check(self._L.pixie_mpm_step(self._h, self._pending_dt, n, self._stream if queued is None else C.c_void_p(queued)), "pixie_mpm_step")
             # The substeps reach their stream only NOW.  A caller synchronised for the reference's eager semantics
             # (`current.wait_stream(side)` right after its p2g2p() loop) waited on a stream that was still empty, so whatever
             # observes or continues the solver on the CURRENT stream has to be ordered after them here.
@@ -197,12 +203,12 @@ class MPM_Simulator_WARP:
     def _get_scalar(self, key):
         self.flush()
         out = C.c_double(0.0)
-        check(_lib.load().pixie_mpm_get_scalar(self._h, key.encode(), C.byref(out)), f"get_scalar({key})")
+        self._check(self._L.pixie_mpm_get_scalar(self._h, key.encode(), C.byref(out)), f"get_scalar({key})")
         return out.value
 
     def _set_scalar(self, key, value):
         self.flush()
-        check(_lib.load().pixie_mpm_set_scalar(self._h, key.encode(), float(value)), f"set_scalar({key})")
+        self._check(self._L.pixie_mpm_set_scalar(self._h, key.encode(), float(value)), f"set_scalar({key})")
 
     def _set_model_scalar(self, attr, value):
         if attr == "gravitational_accelaration":
@@ -228,7 +234,7 @@ class MPM_Simulator_WARP:
         dtype = torch.int32 if name in _INT_FIELDS else torch.float32
         t = self._as_device_tensor(value, dtype)
         self.flush()
-        check(_lib.load().pixie_mpm_set_field(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel(), self._stream),
+        self._check(self._L.pixie_mpm_set_field(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel(), self._stream),
               f"set_field({name})")
 
     def get_field(self, name, out=None):
@@ -247,17 +253,17 @@ class MPM_Simulator_WARP:
         else:
             raise KeyError(name)
         self.flush()
-        check(_lib.load().pixie_mpm_get_field(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), self._stream),
+        self._check(self._L.pixie_mpm_get_field(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), self._stream),
               f"get_field({name})")
         return out
 
     def _fill(self, name, value):
         self.flush()
-        check(_lib.load().pixie_mpm_fill_field(self._h, name.encode(), float(value), self._stream), f"fill({name})")
+        self._check(self._L.pixie_mpm_fill_field(self._h, name.encode(), float(value), self._stream), f"fill({name})")
 
     def _update_mass(self):
         self.flush()
-        check(_lib.load().pixie_mpm_update_mass(self._h, self._stream), "update_mass")
+        self._check(self._L.pixie_mpm_update_mass(self._h, self._stream), "update_mass")
 
     # ------------------------------------------------------------------ initial data
     def load_initial_data_from_torch(self, tensor_x, tensor_volume, tensor_cov=None, n_grid=100, grid_lim=1.0,
@@ -316,7 +322,7 @@ class MPM_Simulator_WARP:
             if key in kwargs:
                 self._set_scalar(key, kwargs[key])
         if "additional_material_params" in kwargs:  # :435-463
-            lib = _lib.load()
+            lib = self._L
             plist = kwargs["additional_material_params"]
             for params in plist:
                 if isinstance(params["material"], str):
@@ -329,12 +335,12 @@ class MPM_Simulator_WARP:
                 vals = np.array([[p["E"], p["nu"], p["density"]] for p in plist], dtype=np.float32).reshape(-1, 3)
                 mats = np.array([int(p["material"]) for p in plist], dtype=np.int32)
                 tb, tv, tm = (torch.from_numpy(a).to(self.device) for a in (boxes, vals, mats))
-                check(lib.pixie_mpm_apply_additional_params_batch(self._h, len(plist), C.c_void_p(tb.data_ptr()), C.c_void_p(tv.data_ptr()),
+                self._check(lib.pixie_mpm_apply_additional_params_batch(self._h, len(plist), C.c_void_p(tb.data_ptr()), C.c_void_p(tv.data_ptr()),
                                                                   C.c_void_p(tm.data_ptr()), self._stream), "apply_additional_params_batch")
                 torch.cuda.current_stream().synchronize()      # the three staging tensors die with this frame
             else:
                 for params in plist:
-                    check(lib.pixie_mpm_apply_additional_params(self._h, d3(params["point"]), d3(params["size"]),
+                    self._check(lib.pixie_mpm_apply_additional_params(self._h, d3(params["point"]), d3(params["size"]),
                                                                 float(params["E"]), float(params["nu"]),
                                                                 float(params["density"]), int(params["material"]),
                                                                 self._stream), "apply_additional_params")
@@ -345,7 +351,7 @@ class MPM_Simulator_WARP:
         reference, only the grid arrays are re-made and dx / inv_dx recomputed; particle fields, model scalars,
         boundary conditions, particle modifiers and the time survive (pixie_mpm_regrid, in place)."""
         self.flush()
-        check(_lib.load().pixie_mpm_regrid(self._h, int(n_grid), float(grid_lim), self._stream), "pixie_mpm_regrid")
+        self._check(self._L.pixie_mpm_regrid(self._h, int(n_grid), float(grid_lim), self._stream), "pixie_mpm_regrid")
         self.n_grid, self.grid_lim = int(n_grid), float(grid_lim)
 
     def set_per_particle(self, E=None, nu=None, density=None, material=None, yield_stress=None):
@@ -362,12 +368,12 @@ class MPM_Simulator_WARP:
     def finalize_mu_lam(self, device="cuda:0"):
         """:465-471"""
         self.flush()
-        check(_lib.load().pixie_mpm_finalize_mu_lam(self._h, 0, self._stream), "finalize_mu_lam")
+        self._check(self._L.pixie_mpm_finalize_mu_lam(self._h, 0, self._stream), "finalize_mu_lam")
 
     def finalize_mu_lam_bulk(self, device="cuda:0"):
         """:505-511"""
         self.flush()
-        check(_lib.load().pixie_mpm_finalize_mu_lam(self._h, 1, self._stream), "finalize_mu_lam_bulk")
+        self._check(self._L.pixie_mpm_finalize_mu_lam(self._h, 1, self._stream), "finalize_mu_lam_bulk")
 
     def reset_densities_and_update_masses(self, all_particle_densities, device="cuda:0"):
         """:640-656"""
@@ -422,7 +428,7 @@ class MPM_Simulator_WARP:
     def _warn_if_particles_lost(self):
         """Mass leaving the simulation must not be silent: the count read back at the last re-binning (no sync)."""
         out = C.c_double(0.0)
-        check(_lib.load().pixie_mpm_get_scalar(self._h, b"lost_particles_seen", C.byref(out)), "get_scalar")
+        self._check(self._L.pixie_mpm_get_scalar(self._h, b"lost_particles_seen", C.byref(out)), "get_scalar")
         lost = int(out.value)
         if lost > getattr(self, "_lost_reported", 0):
             import warnings
@@ -433,25 +439,32 @@ class MPM_Simulator_WARP:
     p2g2p_n = run
 
     def phase(self, phase, dt):
-        """Test hook: 0 = modifiers+stress+P2G, 1 = grid update+damping+BCs, 2 = G2P."""
+        """Test hook (diag=True solvers only): 0 = modifiers+stress+P2G, 1 = grid update+damping+BCs, 2 = G2P."""
+        self._need_diag("phase()")
         self.flush()
-        check(_lib.load().pixie_mpm_phase(self._h, int(phase), float(dt), self._stream), "pixie_mpm_phase")
+        self._check(self._L.pixie_mpm_phase(self._h, int(phase), float(dt), self._stream), "pixie_mpm_phase")
 
     @property
     def out_of_bounds(self):
         cnt = C.c_int64(0)
         self.flush()
-        check(_lib.load().pixie_mpm_out_of_bounds(self._h, C.byref(cnt), self._stream), "out_of_bounds")
+        self._check(self._L.pixie_mpm_out_of_bounds(self._h, C.byref(cnt), self._stream), "out_of_bounds")
         return cnt.value
 
+    def _need_diag(self, what):
+        if not self._diag:
+            raise _lib.PixieHipError(f"{what} is a diagnostic of the PIXIE_DIAG build: create the solver with MPM_Simulator_WARP(..., diag=True)")
+
     def set_profile(self, on=True):
+        self._need_diag("set_profile()")
         self._set_scalar("profile", 1.0 if on else 0.0)
 
     def kernel_times(self):
         """(mean fused-particle-kernel ms, mean grid-kernel ms, launches) since the last call."""
+        self._need_diag("kernel_times()")
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
         self.flush()
-        check(_lib.load().pixie_mpm_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)), "kernel_times")
+        self._check(self._L.pixie_mpm_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)), "kernel_times")
         return a.value, b.value, n.value
 
     # ------------------------------------------------------------------ import / export (:659-741)
@@ -514,13 +527,13 @@ class MPM_Simulator_WARP:
     def export_particle_R_to_torch(self, device="cuda:0"):
         out = self._export_view("R", (self.n_particles, 9))
         self.flush()
-        check(_lib.load().pixie_mpm_export_R(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_R")
+        self._check(self._L.pixie_mpm_export_R(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_R")
         return out
 
     def export_particle_cov_to_torch(self, device="cuda:0"):
         out = self._export_view("cov", (self.n_particles * 6,))
         self.flush()
-        check(_lib.load().pixie_mpm_export_cov(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_cov")
+        self._check(self._L.pixie_mpm_export_cov(self._h, C.c_void_p(out.data_ptr()), self._stream), "export_cov")
         return out
 
     def export_frame_for_rendering(self, gs_num, scale_origin, original_mean_pos, rotation_matrices, z_shift_value=0.0,
@@ -536,7 +549,7 @@ class MPM_Simulator_WARP:
         pos = torch.empty((int(gs_num), 3), dtype=torch.float32, device=self.device)
         cov = torch.empty((int(gs_num), 6), dtype=torch.float32, device=self.device) if with_cov else None
         self.flush()
-        check(_lib.load().pixie_mpm_export_frame(self._h, int(gs_num), d3([1.0, 1.0, 1.0 + float(z_shift_value)]), float(scale_origin),
+        self._check(self._L.pixie_mpm_export_frame(self._h, int(gs_num), d3([1.0, 1.0, 1.0 + float(z_shift_value)]), float(scale_origin),
                                                  d3(mean), (C.c_double * 9)(*M.reshape(-1)), C.c_void_p(pos.data_ptr()),
                                                  C.c_void_p(cov.data_ptr()) if with_cov else None, self._stream), "export_frame")
         return pos, cov
@@ -561,7 +574,7 @@ class MPM_Simulator_WARP:
         bc.end_time = float(kw.get("end_time", 999.0))
         bc.friction = float(kw.get("friction", 0.0))
         self.flush()
-        check(_lib.load().pixie_mpm_add_bc(self._h, C.byref(bc)), "pixie_mpm_add_bc")
+        self._check(self._L.pixie_mpm_add_bc(self._h, C.byref(bc)), "pixie_mpm_add_bc")
 
     def add_surface_collider(self, point, normal, surface="sticky", friction=0.0, start_time=0.0, end_time=999.0):
         """:749-843"""
@@ -593,7 +606,7 @@ class MPM_Simulator_WARP:
         for nm in ("half_height", "radius", "rotation_scale", "translation_scale", "start_time", "end_time"):
             setattr(pm, nm, float(kw.get(nm, 0.0)))
         self.flush()
-        check(_lib.load().pixie_mpm_add_particle_modifier(self._h, C.byref(pm), self._stream), "add_particle_modifier")
+        self._check(self._L.pixie_mpm_add_particle_modifier(self._h, C.byref(pm), self._stream), "add_particle_modifier")
 
     def add_impulse_on_particles(self, force, dt, point=[1, 1, 1], size=[1, 1, 1], num_dt=1, start_time=0.0,
                                  device="cuda:0"):

@@ -155,7 +155,7 @@ class HipOps:
                 desc.d_out_amax = out_amax.data_ptr()
         if self.record_variant:   # profilers: which kernel instantiation this launch is (grouping key of rocprofv3)
             sl = C.c_int(1)
-            self.last_variant = (int(self.lib.pixie_conv_kernel_variant(C.byref(desc), C.byref(sl))), int(sl.value))
+            self.last_variant = (int(_lib.load(diag=True).pixie_conv_kernel_variant(C.byref(desc), C.byref(sl))), int(sl.value))   # a pure function of the descriptor
         check(self.lib.pixie_conv3d_forward(C.byref(desc), self.stream), "pixie_conv3d_forward")
         if desc.d_out_stats:
             sums = torch.empty((cout, 2), device=self.device, dtype=torch.float64)

@@ -8,7 +8,7 @@ sc = mpm_ball_scene(20000, seed=1)
 n = 20000
 rng = np.random.default_rng(0)
 v0 = (0.5 * rng.normal(size=(n, 3))).astype(np.float32)
-h = MPM_Simulator_WARP(10)
+h = MPM_Simulator_WARP(10, diag=True)
 h.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]), n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
 apply_scene(h, sc)
 o = OracleMPM(n, sc["n_grid"], sc["grid_lim"], "f32"); o.load_initial_data(sc["x"], sc["vol"], sc["cov"]); apply_scene(o, sc)

@@ -26,7 +26,10 @@ def main():
         ng = sc["n_grid"]
     else:
         sc = mpm_ball_scene(n, seed=0, n_grid=ng, scenario=scenario, dt=float(os.environ.get("PIXIE_MPM_DT", "1e-4")))
-    s = MPM_Simulator_WARP(10)
+    # PIXIE_MPM_DIAG=1 (implied by PIXIE_MPM_TRACE): the handle lives in libpixie_hip_diag.so -- same sources and kernels + the per-launch
+    # event timing and the trace; without it the product library is timed and the per-kernel columns read 0
+    diag = bool(os.environ.get("PIXIE_MPM_TRACE")) or os.environ.get("PIXIE_MPM_DIAG", "0") != "0"
+    s = MPM_Simulator_WARP(10, diag=diag)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                    n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
     if plastic:
@@ -55,16 +58,18 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rebins_timed = int(s._get_scalar("n_rebins")) - rebins0
-    s.set_profile(True)
-    s.run(sc["dt"], 128)
-    torch.cuda.synchronize()
-    p_ms, g_ms, nl = s.kernel_times()
-    s.set_profile(False)
+    p_ms = g_ms = 0.0
+    if diag:
+        s.set_profile(True)
+        s.run(sc["dt"], 128)
+        torch.cuda.synchronize()
+        p_ms, g_ms, nl = s.kernel_times()
+        s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
-    print(f"n={n} ng={ng} resort={resort} {scenario} occ={os.environ.get('PIXIE_MPM_OCC', '5')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', '256')} "
+    print(f"n={n} ng={ng} resort={resort} {scenario} lib={'diag' if diag else 'product'} occ={os.environ.get('PIXIE_MPM_OCC', '5')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', '256')} "
           f"bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} v0={os.environ.get('PIXIE_MPM_V0', '0')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
-          f"({212.0 * n / (p_ms * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
+          f"({212.0 * n / (max(p_ms, 1e-9) * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
           f"active blocks {int(s._get_scalar('n_active_blocks'))} rebins {int(s._get_scalar('n_rebins'))} (timed region: {rebins_timed}) slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "
           f"finite {bool(torch.isfinite(s.get_field('x')).all())}", flush=True)
 

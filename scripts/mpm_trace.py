@@ -14,7 +14,7 @@ from pixie_amd.synthetic import apply_scene, mpm_ball_scene  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ng = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 sc = mpm_ball_scene(n, seed=0, n_grid=ng)
-s = MPM_Simulator_WARP(10)
+s = MPM_Simulator_WARP(10, diag=True)
 s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
                                n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
 apply_scene(s, sc)
@@ -25,7 +25,7 @@ s.run(sc["dt"], 3)     # the buffer keeps the last substep
 torch.cuda.synchronize()
 s._set_scalar("trace", 0)
 items = int(s._get_scalar("n_work_items"))
-rd = C.CDLL(L.LIB_PATH)["_ZN5pixie14mpm_trace_readEPyi"]
+rd = C.CDLL(L.DIAG_LIB_PATH)["_ZN5pixie14mpm_trace_readEPyi"]
 rd.argtypes = [C.c_void_p, C.c_int]
 m = min(items, 32768)
 buf = np.zeros(m * 8, dtype=np.uint64)

@@ -14,11 +14,11 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     """A fresh checkout has no built artefacts (they are git-ignored): build what is MISSING once -- the product library with
-    hipcc (cross-compiles without a GPU) and the oracle's C restatement with gcc -- exactly as __graft_entry__.build() does.
+    hipcc (cross-compiles without a GPU; the product library and its -DPIXIE_DIAG twin) and the oracle's C restatement with gcc -- exactly as __graft_entry__.build() does.
     Never rebuilds something that exists (on the GPU box the prebuilt files travel with the tree)."""
-    lib = os.path.join(REPO, "pixie_amd", "libpixie_hip.so")
+    libs = [os.path.join(REPO, "pixie_amd", n) for n in ("libpixie_hip.so", "libpixie_hip_diag.so")]
     oracle_so = [os.path.join(REPO, "oracle", "build", n) for n in ("libmpm_oracle_f32.so", "libmpm_oracle_f64.so")]
-    if os.path.exists(lib) and all(os.path.exists(p) for p in oracle_so):
+    if all(os.path.exists(p) for p in libs + oracle_so):
         return
     try:
         import __graft_entry__

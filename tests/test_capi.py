@@ -12,20 +12,42 @@ from pixie_amd import _lib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
+def header_symbols(diag=False):
+    """entry points include/pixie_hip.h declares: without / with its #ifdef PIXIE_DIAG section"""
     text = open(os.path.join(REPO, "include", "pixie_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pixie_[A-Za-z0-9_]+)\s*\(", text)))
+    head, sep, tail = text.partition("#ifdef PIXIE_DIAG")
+    assert sep and "#endif" in tail
+    diag_part, _, rest = tail.partition("#endif")
+    names = lambda t: set(re.findall(r"\b(pixie_[A-Za-z0-9_]+)\s*\(", t))
+    return sorted(names(head) | names(rest) | (names(diag_part) if diag else set()))
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("pixie_")}
 
 
 def test_library_exports_every_declared_symbol():
+    """header == ctypes table == exported symbols, for BOTH builds: libpixie_hip.so (the product: no diagnostic entry point, no
+    trace buffer) and libpixie_hip_diag.so (-DPIXIE_DIAG: the product's symbols + the header's diagnostic section)."""
     lib = _lib.load()
     names = header_symbols()
     assert len(names) >= 28
     for nm in names:
         assert hasattr(lib, nm), f"{nm} declared in include/pixie_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert exported(_lib.LIB_PATH) == set(names), exported(_lib.LIB_PATH) ^ set(names)
     assert lib.pixie_build_arch() == b"gfx950"
+    diag_names = header_symbols(diag=True)
+    assert set(diag_names) - set(names) == set(_lib.DIAG_SIGNATURES) == {"pixie_mpm_phase", "pixie_mpm_kernel_times", "pixie_conv_kernel_variant"}
+    dlib = _lib.load(diag=True)
+    assert exported(_lib.DIAG_LIB_PATH) == set(diag_names), exported(_lib.DIAG_LIB_PATH) ^ set(diag_names)
+    assert dlib.pixie_build_arch() == b"gfx950"
+    import subprocess
+    syms = lambda p: subprocess.check_output(["nm", "-D", p], text=True)     # the 2 MB device trace buffer's host shadow + its reader
+    assert "mpm_trace" in syms(_lib.DIAG_LIB_PATH) and "mpm_trace" not in syms(_lib.LIB_PATH)
 
 
 def test_struct_layouts_match_header(tmp_path):

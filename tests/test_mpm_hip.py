@@ -26,9 +26,10 @@ def rel_l2(a, b):
 SCATTER_MODES = (64, 32)
 
 
-def make_hip(scene, per_particle=True, bits=None):
+def make_hip(scene, per_particle=True, bits=None, diag=False):
+    """diag=True: the handle lives in libpixie_hip_diag.so (same sources, -DPIXIE_DIAG), which adds the per-phase entry point."""
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
-    s = MPM_Simulator_WARP(10)
+    s = MPM_Simulator_WARP(10, diag=diag)
     s.load_initial_data_from_torch(torch.from_numpy(scene["x"]), torch.from_numpy(scene["vol"]), torch.from_numpy(scene["cov"]),
                                    n_grid=scene["n_grid"], grid_lim=scene["grid_lim"])
     apply_scene(s, scene, per_particle=per_particle)
@@ -61,7 +62,7 @@ def test_phase_by_phase_parity(hip_device):
     v0 = (0.5 * rng.normal(size=(n, 3))).astype(np.float32)
     C0 = (2.0 * rng.normal(size=(n, 3, 3))).astype(np.float32)
     Ft0 = (np.eye(3) + 0.03 * rng.normal(size=(n, 3, 3))).astype(np.float32)
-    h, o = make_hip(sc, bits=64), make_oracle(sc, "f32")   # the exact accumulation mode; the packed one: test_packed_scatter_parity
+    h, o = make_hip(sc, bits=64, diag=True), make_oracle(sc, "f32")   # the exact accumulation mode; the packed one: test_packed_scatter_parity
     h.set_field("v", v0); h.set_field("C", C0.reshape(n, 9)); h.set_field("F_trial", Ft0.reshape(n, 9))
     o.field("v")[:] = v0; o.field("C")[:] = C0; o.field("F_trial")[:] = Ft0
     dt = sc["dt"]
@@ -250,7 +251,7 @@ def test_sparse_tile_publishing_bit_identical(hip_device, bits):
     res = {}
     variants = [(0, 4), (1, 4), (1, 1), (0, 1), (1, 2)]   # (sparse tiles, grid kernel's loads in flight per candidate block)
     for sparse, rb in variants:
-        h = make_hip(sc, bits=bits)
+        h = make_hip(sc, bits=bits, diag=True)
         h._set_scalar("sparse_tiles", sparse)
         h._set_scalar("grid_rb", rb)
         h.run(sc["dt"], 40)
@@ -381,7 +382,7 @@ def test_mass_contrast_selects_the_exact_scatter(hip_device):
     assert sel.sum() > 500
     errs = {}
     for mode in (0, 32, 64):
-        h = make_hip(sc)
+        h = make_hip(sc, diag=True)
         h._set_scalar("scatter_bits", mode)
         h.set_field("v", v0); h.set_field("F_trial", Ft0.reshape(n, 9))
         h.phase(0, dt); h.phase(1, dt)
@@ -407,7 +408,7 @@ def test_packed_scatter_parity(hip_device):
     v0 = (0.5 * rng.normal(size=(n, 3))).astype(np.float32)
     C0 = (2.0 * rng.normal(size=(n, 3, 3))).astype(np.float32)
     Ft0 = (np.eye(3) + 0.03 * rng.normal(size=(n, 3, 3))).astype(np.float32)
-    h, o = make_hip(sc), make_oracle(sc, "f32")
+    h, o = make_hip(sc, diag=True), make_oracle(sc, "f32")
     h._set_scalar("scatter_bits", 32)
     h.set_field("v", v0); h.set_field("C", C0.reshape(n, 9)); h.set_field("F_trial", Ft0.reshape(n, 9))
     o.field("v")[:] = v0; o.field("C")[:] = C0; o.field("F_trial")[:] = Ft0
@@ -471,7 +472,7 @@ def test_inverted_particles_take_the_svd_route(hip_device):
     Ft0 = Ft0.astype(np.float32)
     assert (np.linalg.det(Ft0.astype(np.float64)) < 0).sum() > 1500
     # stress of the first substep: the branch under test, before any dynamics amplify differences
-    h0, o0 = make_hip(sc, per_particle=False), make_oracle(sc, "f64", per_particle=False)
+    h0, o0 = make_hip(sc, per_particle=False, diag=True), make_oracle(sc, "f64", per_particle=False)
     h0.set_field("F_trial", Ft0.reshape(n, 9)); o0.field("F_trial")[:] = Ft0
     h0.phase(0, sc["dt"])
     o0.phase("zero_grid"); o0.phase("pre_p2g", sc["dt"]); o0.phase("compute_stress", sc["dt"])
