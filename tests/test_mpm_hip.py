@@ -24,6 +24,11 @@ def rel_l2(a, b):
 # The two accumulation modes of the P2G scatter (csrc/mpm.hip): 64 = exact 64-bit fixed point, 32 = packed pairs of 32-bit
 # sums (half the LDS atomics).  Every rollout test holds BOTH to the same particle-level bars.
 SCATTER_MODES = (64, 32)
+# Where a quantity cannot meet 1e-4 against the float64 oracle for a reason that lies in float32 itself (x += dt v below ulp(x);
+# a yield surface crossed on the other side), the yardstick is the distance of the float32 ORACLE -- the reference's algorithm
+# in the reference's precision -- from the float64 one, and the bar is DRIFT_K times it.  Measured over every test of this file
+# the product sits between 0.4 and 1.0 of that yardstick (profiles/r5a_pytest_mpm_numbers.txt; 4.0 was the bar until round 4).
+DRIFT_K = 1.5
 
 
 def make_hip(scene, per_particle=True, bits=None, diag=False):
@@ -115,7 +120,7 @@ def _assert_rollout_parity(h, o32, o64, sc, tag):
     # displacement (the signal itself, not the O(1) coordinate)
     disp_h, disp_o = x_h - sc["x"], o64.field("x") - sc["x"]
     drift_d = rel_l2(o32.field("x") - sc["x"], disp_o)
-    assert rel_l2(disp_h, disp_o) < max(1e-4, 4 * drift_d)
+    assert rel_l2(disp_h, disp_o) < max(1e-4, DRIFT_K * drift_d)
     # v and C are compared on the scale of the velocity field: C is a velocity gradient, so its natural unit is
     # rms|v| / dx (in free fall C is ~0 and a norm-relative error would compare roundoff with roundoff).
     n = x_h.shape[0]
@@ -125,7 +130,7 @@ def _assert_rollout_parity(h, o32, o64, sc, tag):
         drift = float(np.linalg.norm(o32.field(name).astype(np.float64) - o64.field(name)) / np.sqrt(n)) / scale
         err = float(np.linalg.norm(got.astype(np.float64) - o64.field(name)) / np.sqrt(n)) / scale
         print(f"{tag} {name}: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  (scale {scale:.3e})")
-        assert err < max(1e-4, 4 * drift)
+        assert err < max(1e-4, DRIFT_K * drift)
     assert h.out_of_bounds == 0
 
 
@@ -491,7 +496,7 @@ def test_inverted_particles_take_the_svd_route(hip_device):
     e_x = rel_l2(x_h, o64.field("x")); e_F = rel_l2(F_h, o64.field("F_trial"))
     print(f"inverted particles: x {e_x:.2e} (oracle f32 drift {d_x:.2e}), F_trial {e_F:.2e} (drift {d_F:.2e}); still inverted: "
           f"{int((np.linalg.det(F_h.astype(np.float64)) < 0).sum())}")
-    assert e_x < 1e-4 and e_F < max(1e-4, 4 * d_F)
+    assert e_x < 1e-4 and e_F < max(1e-4, DRIFT_K * d_F)
     assert h.out_of_bounds == 0
 
 
@@ -512,7 +517,7 @@ PLASTIC = [
 def test_plastic_materials_rollout(hip_device, name, mid, extra, bits):
     """Every constitutive branch of compute_stress_from_F_trial (mpm_utils.py:467-526) on the device, 60 substeps from a
     deformed state, against the float64 oracle.  Tolerances: x, F at the north-star 1e-4; every quantity additionally
-    gets k = 4 times the distance of the float32 ORACLE from the float64 oracle (the same restatement run in the
+    gets DRIFT_K times the distance of the float32 ORACLE from the float64 oracle (the same restatement run in the
     reference's own precision), because the return mappings are discontinuous maps of F (yield / no yield, the sand
     cone's three cases): a particle sitting within rounding distance of the yield surface takes the other branch in
     float32, which is a property of the reference's arithmetic, not of this implementation.  The measured numbers are
@@ -541,7 +546,7 @@ def test_plastic_materials_rollout(hip_device, name, mid, extra, bits):
         err = float(np.linalg.norm(get(h, f).reshape(shape).astype(np.float64) - ref) / scale)
         drift = float(np.linalg.norm(o32.field(f).astype(np.float64) - ref) / scale)
         report.append(f"{f}: hip {err:.2e} / f32-oracle {drift:.2e}")
-        assert err < max(1e-4, 4 * drift), (name, f, err, drift)
+        assert err < max(1e-4, DRIFT_K * drift), (name, f, err, drift)
     print(f"{name}: " + "; ".join(report))
     assert float(np.abs(get(h, "stress")).max()) > 0
     if mid != 6:
@@ -556,7 +561,7 @@ def test_rollout_parity_config3(hip_device, bits):
     so its trajectory is a committed fixture (tests/golden/make_mpm_golden.py; tests/test_mpm_oracle.py re-runs its first
     checkpoint live): every 16th particle's x, v, C, F_trial at substeps 20 / 100 / 500 / 1000, whole-population norms,
     momentum and centre of mass, and the float32 oracle's own drift from the float64 one.
-    Bar: x and F_trial <= 1e-4 outright; the displacement, v and C <= max(1e-4, 4 x the float32 oracle's drift), v and C
+    Bar: x and F_trial <= 1e-4 outright; the displacement, v and C <= max(1e-4, DRIFT_K x the float32 oracle's drift), v and C
     measured on the scale of the velocity field as in test_rollout_parity."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpm_config3.npz"))
@@ -596,13 +601,13 @@ def test_rollout_parity_config3(hip_device, bits):
               f"{e_norm.max():.2e} (f32 oracle {agg[:4].max():.2e}), momentum {e_p:.2e} ({agg[4]:.2e}), centre of mass {e_com:.2e} ({agg[5]:.2e})")
         assert np.isfinite(x).all() and np.isfinite(v).all()
         assert e_x < 1e-4 and e_F < 1e-4
-        assert e_disp < max(1e-4, 4 * d_disp)
-        assert e_v < max(1e-4, 4 * dv) and e_C < max(1e-4, 4 * dC)
+        assert e_disp < max(1e-4, DRIFT_K * d_disp)
+        assert e_v < max(1e-4, DRIFT_K * dv) and e_C < max(1e-4, DRIFT_K * dC)
         # aggregates over all 100 000 particles: systematic (not averaging-out) errors show here.  float32 positions lose
         # the part of dt * v below half an ulp of x (dt * v ~ 1e-7 ... 1e-6 against ulp(x) = 1.2e-7 in this quiet scene),
         # in the oracle's float32 build exactly as on the device, hence the float32 oracle's own numbers as the yardstick
-        assert (e_norm < np.maximum(1e-4, 4 * agg[:4])).all(), (e_norm, agg[:4])
-        assert e_p < max(1e-4, 4 * agg[4]) and e_com < max(1e-7, 4 * agg[5])
+        assert (e_norm < np.maximum(1e-4, DRIFT_K * agg[:4])).all(), (e_norm, agg[:4])
+        assert e_p < max(1e-4, DRIFT_K * agg[4]) and e_com < max(1e-7, DRIFT_K * agg[5])
     assert h.out_of_bounds == 0 and int(g["oob"][0]) == 0
     assert abs(h.time - 1000 * sc["dt"]) < 1e-9
 
@@ -614,7 +619,7 @@ def test_plastic_reference_configs_100k(hip_device, material, bits):
     n_grid 200 / 120, substep 2e-5 / 1e-5, gravity, damping, boundary conditions) with 100 000 particles for 200 substeps,
     against the float64 C oracle's committed trajectory (tests/golden/make_mpm_plastic_golden.py, which perturbs the initial
     F and v so that the return mappings work from the first substep).  Bar: x and F <= 1e-4 outright; v (on the scale of
-    rms|v|) and the yield stress <= max(1e-4, 4 x the float32 oracle's own drift)."""
+    rms|v|) and the yield stress <= max(1e-4, DRIFT_K x the float32 oracle's own drift)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
@@ -641,7 +646,7 @@ def test_plastic_reference_configs_100k(hip_device, material, bits):
               f"yield stress {e_ys:.2e} ({d_ys:.2e})")
         assert np.isfinite(x).all() and np.isfinite(F).all()
         assert e_x < 1e-4 and e_F < 1e-4
-        assert e_v < max(1e-4, 4 * d_v) and e_ys < max(1e-4, 4 * d_ys)
+        assert e_v < max(1e-4, DRIFT_K * d_v) and e_ys < max(1e-4, DRIFT_K * d_ys)
     print(f"{material}: {100 * float(g['yielded_fraction']):.0f} % of the particles yielded within the 200 substeps")
     assert float(g["yielded_fraction"]) > 0.05                    # the return mapping is really at work in this scene
     assert h.out_of_bounds == 0 and int(g["oob"]) == 0
@@ -673,7 +678,7 @@ def test_boundary_conditions_and_modifiers(hip_device):
     # the common bar of this file (this test alone allowed 1e-3).  The float32 and float64 oracles differ by
     # ~1e-2 here for a systematic reason -- the velocity pins and the impulse window act on float32 time / float32 state --
     # and the HIP solver follows the float32 arithmetic, so it is ALSO held to the float32 oracle directly.
-    assert err < max(1e-4, 4 * drift)
+    assert err < max(1e-4, DRIFT_K * drift)
     assert direct < 1e-4
     assert rel_l2(get(h, "F_trial").reshape(-1, 3, 3), o.field("F_trial")) < 1e-4
     # 20 more: through the cuboid's end_time and its 15-substep "reset" window, which zeroes the whole grid
@@ -685,7 +690,7 @@ def test_boundary_conditions_and_modifiers(hip_device):
     drift = rel_l2(o32.field("v"), o.field("v"))
     err = rel_l2(get(h, "v"), o.field("v"))
     print(f"bc test v @50: hip-vs-f64 {err:.3e}  oracle f32-vs-f64 {drift:.3e}  hip-vs-oracle-f32 {rel_l2(get(h, 'v'), o32.field('v')):.3e}")
-    assert err < max(1e-4, 4 * drift)
+    assert err < max(1e-4, DRIFT_K * drift)
 
 
 def test_regrid_after_load_keeps_everything_but_the_grid(hip_device):
@@ -723,7 +728,7 @@ def test_regrid_after_load_keeps_everything_but_the_grid(hip_device):
     err = float(np.linalg.norm(get(h, "v") - res["f64"]["v"]) / np.sqrt(6000)) / v_rms
     drift = float(np.linalg.norm(res["f32"]["v"] - res["f64"]["v"]) / np.sqrt(6000)) / v_rms
     print(f"regrid: v hip-vs-f64 {err:.2e}, oracle f32-vs-f64 {drift:.2e}")
-    assert err < max(1e-4, 4 * drift)
+    assert err < max(1e-4, DRIFT_K * drift)
     assert h.out_of_bounds == 0
 
 

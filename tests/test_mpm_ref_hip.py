@@ -21,6 +21,9 @@ import pytest
 
 from tests._mpm_ref_driver import ProductAdapter, STATE_FIELDS, load_fixture, run
 
+# bar = DRIFT_K x the float32 yardstick where the 1e-5 / 1e-4 floor does not decide (tests/test_mpm_hip.py explains; measured <= 1.00)
+DRIFT_K = 1.5
+
 pytestmark = pytest.mark.gpu
 
 SCENES = load_fixture(os.path.join(os.path.dirname(__file__), "golden", "mpm_ref_golden.npz"))
@@ -57,9 +60,9 @@ def test_product_tracks_the_reference_code_over_a_rollout(hip_device, name, bits
     float64 result, and after 150 substeps there are two of them: the fixture's float32 run of the reference's code -- whose SVDs
     come from LAPACK, accurate to an ulp -- and the float32 build of the C oracle, whose Jacobi SVD runs in float32 as an SVD on
     a GPU does (a plastic rollout feeds that noise back through the yield surface every substep: metal v 1.4e-4 against
-    8.8e-6).  Bar per field and checkpoint: max(1e-4, 4 x the larger of the two).  Measured (profiles/r4x, r4end): the product is
-    below the float32 oracle's own distance on every field -- metal v 1.15e-4, C 3.3e-4, stress 3.9e-4; sand v 4.1e-5; tree v
-    3.3e-4 (the reference's float32 run: 5.6e-4)."""
+    8.8e-6).  Bar per field and checkpoint: max(1e-4, DRIFT_K x the larger of the two).  Measured (profiles/r5a): the product is at or below
+    the yardstick on every field (worst ratio 1.00, the displacement) -- with the single-decomposition constitutive path metal v
+    2.2e-5, C 8.0e-5, stress 8.9e-5; sand v 1.4e-6; tree v 3.0e-4 (the reference's float32 run: 4.1e-4)."""
     _compare(LONG[name], name, bits, rollout=True)
 
 
@@ -86,11 +89,11 @@ def _compare(entry, name, bits, rollout=False):
             want, got = ref[f"k{cp}/{f}"], snaps[cp][f].reshape(ref[f"k{cp}/{f}"].shape)
             if f == "x":
                 want, got = want - arrays["x0"], got - arrays["x0"]
-            err, bar = rel(got, want), (max(1e-5, 2 * drift[f]) if f == "x" else max(1e-5, 4 * drift[f]))
+            err, bar = rel(got, want), max(1e-5, DRIFT_K * drift[f])
             extra = ""
             if rollout:
                 o = o32[cp][f].reshape(ref[f"k{cp}/{f}"].shape) - (arrays["x0"] if f == "x" else 0.0)
-                bar = max(1e-4, 4 * max(drift[f], rel(o, want)))
+                bar = max(1e-4, DRIFT_K * max(drift[f], rel(o, want)))
                 extra = f", float32 oracle {rel(o, want):.2e}"
             report.append(f"k{cp} {f}: {err:.2e} (reference f32 drift {drift[f]:.2e}{extra})")
             if not err < bar:
