@@ -111,6 +111,7 @@ def parse():
     ap.add_argument("--no-shipped-shape", action="store_true", help="skip the 64^3 x 768 fp16-grid sub-record")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32-MFMA sub-record of the same U-Net step")
     ap.add_argument("--no-mpm-large", action="store_true", help="skip the 1M-particle / n_grid 120 MPM leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end BASELINE configs[2] scene (U-Net -> field transfer -> MPM rollout)")
     ap.add_argument("--no-mpm-plastic", action="store_true", help="skip the sand / snow / metal / mixed-material 1M-particle legs")
     ap.add_argument("--mpm-plastic-substeps", type=int, default=400)
     ap.add_argument("--no-unet-256", action="store_true", help="skip the 256^3 x 128 U-Net sub-record (BASELINE configs[4]'s per-GPU grid)")
@@ -163,7 +164,7 @@ def pin_rank_resources(rank, world):
     which would make the CPU-side set-up of every rank single-threaded) and keep the ranks off each other's cores."""
     cores = os.cpu_count() or 1
     if world <= 1:
-        return cores
+        return torch.get_num_threads()      # what the CPU legs actually run on (torch's default: the physical cores)
     share = max(1, cores // world)
     try:
         avail = sorted(os.sched_getaffinity(0))
@@ -338,8 +339,9 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
             # so the matrix pipe is doing 3x that.  peak = dense f16 MFMA peak; frac = achieved/peak (conservative).
             roof = {"bound": "mfma", "kernel": "conv3d_f16x3_c64_fullres_kernel (= conv3d_f16x3_kernel<3,2,4>; 64->64 3^3 conv, %d^3)" % D, "achieved": round(ach, 2),
                     "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
-                    "traffic": (load_traffic().get("conv_64_64_128") or {}).get("hbm_bytes_per_launch"),
-                    "traffic_source": "profiles/pmc_traffic.json" if load_traffic().get("conv_64_64_128") else None,
+                    # the PMC reading of THIS layer shape (profiles/pmc_traffic.json key conv_64_64_<D>); None where no pass was taken
+                    "traffic": (load_traffic().get(f"conv_64_64_{D}") or {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": "profiles/pmc_traffic.json" if load_traffic().get(f"conv_64_64_{D}") else None,
                     "avg_launch_ms": round(ms, 4), "launches": agg[dom_key][1], "flop_per_launch": fl,
                     "avg_launch_ms_dual_stream": (round(agg_timed[dom_key][0] / agg_timed[dom_key][1], 4) if dom_key in agg_timed else None),
                     "launch_timing": "HIP events on the launch stream around every launch of the Python plan walk; single-stream pass of 2 scenes right after the timed region (the timed region replays HIP graphs; see bench.py)",
@@ -525,6 +527,21 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatt
     return out
 
 
+def bench_mpm_floor(device, n_grid, substeps=3000):
+    """What a substep costs when there is (almost) nothing to do: the same two launches per substep on a 2 000-particle ball in the
+    same grid -- launch boundaries, one work item's life, the grid kernel's dependent round trips.  The 100 k-particle scene of
+    BASELINE configs[2] (26.7 MB per substep = 3.3 us at 8 TB/s) sits a few us above this floor, which is why its HBM-roofline
+    fraction is a statement about launch latency, not about the kernels (profiles/r4g_*)."""
+    sc = mpm_ball_scene(2000, seed=3, n_grid=n_grid)
+    s = _mpm_solver(sc)
+    s.run(sc["dt"], 100)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.run(sc["dt"], substeps)
+    torch.cuda.synchronize()
+    return 1e6 * (time.perf_counter() - t0) / substeps
+
+
 def bench_mpm_multi_scene(args, device, particles, n_grid, substeps, n_scenes):
     """BASELINE configs[3] runs a batch of scenes.  One 100 k-particle scene fills 41 % of the chip's workgroup slots and its
     launches are latency-bound, so several independent scenes on their own HIP streams (one host thread each: the launch
@@ -559,6 +576,48 @@ def bench_mpm_multi_scene(args, device, particles, n_grid, substeps, n_scenes):
             "us_per_substep_per_scene": 1e6 * dt / substeps, "finite": finite, "repetitions_us_per_substep": [round(1e6 * r / substeps, 2) for r in reps],
             "timing": "median of 3 repetitions",
             "config": {"workload": f"{n_scenes} independent scenes of {particles} particles (n_grid {n_grid}) on {n_scenes} HIP streams of one GPU"}}
+
+
+def bench_pipeline(args, device, substeps=1000):
+    """BASELINE configs[2] as ONE timed scene, device-resident end to end: seeded 128^3 x 64 feature grid -> both networks
+    (+ combine) -> un-scaling + K = 10 field transfer onto 100 k particles -> solver set-up -> `substeps` substeps
+    (pixie_amd/pipeline.py; the reference: pixie/utils.py:736-779 + gs_simulation.py:483-531,633-634, three programs and two file
+    hand-overs).  One warm scene, then the mean of two; parts from HIP events on the stream, total = wall clock with a device
+    synchronisation at both ends.  The materials are whatever the randomly initialised networks predict (a mixed-material ball),
+    un-scaled into the CFL-safe ranges of pixie_amd.synthetic.PIPELINE_RANGES."""
+    from pixie_amd.pipeline import neural_scene_rollout
+    from pixie_amd.synthetic import pipeline_scene
+    from pixie_amd.unet import RegressionUNet, SegmentationUNet
+    D, C = args.grid, args.feature_channels
+    kw = dict(feature_channels=C, cond_dim=32, model_channels=64, num_res_blocks=3, channel_mult=(1, 1, 2, 4), attention_resolutions=(), grid_size=D)
+    seg, cont = SegmentationUNet(num_classes=8, **kw), RegressionUNet(out_channels=3, **kw)
+    seg.load_numpy_state(synthetic_state_dict(seg.cfg, 0)); cont.load_numpy_state(synthetic_state_dict(cont.cfg, 1000))
+    seg, cont = seg.to(device).eval(), cont.to(device).eval()
+    sc = pipeline_scene(D, C, args.particles, seed=0, n_grid=args.n_grid)
+    feat, mask = torch.from_numpy(sc["feat"]).to(device), torch.from_numpy(sc["mask"]).to(device)
+    x0, vol = torch.from_numpy(sc["x"]).to(device), torch.from_numpy(sc["vol"]).to(device)
+
+    def one(timings=None):
+        return neural_scene_rollout(seg, cont, feat, mask, x0, vol, n_grid=sc["n_grid"], grid_lim=sc["grid_lim"], dt=sc["dt"], n_substeps=substeps,
+                                    params=sc["params"], min_bounds=sc["min_bounds"], max_bounds=sc["max_bounds"],
+                                    to_field_frame=lambda x: (x - 1.0) * sc["field_scale"], configure=lambda s: s.add_bounding_box(),
+                                    ranges=sc["ranges"], timings=timings)
+    for _ in range(3):      # set-up passes: pack the weights, capture and settle the networks' graphs (as in bench_unet)
+        one()
+    torch.cuda.synchronize()
+    parts, walls = {}, []
+    for _ in range(2):
+        tm = {}
+        t0 = time.perf_counter()
+        solver, _, _ = one(tm)
+        walls.append(1e3 * (time.perf_counter() - t0))
+        for k_, v_ in tm.items():
+            parts[k_] = parts.get(k_, 0.0) + v_ / 2
+    mats = torch.bincount(solver.get_field("material").to(torch.int64), minlength=8).tolist()
+    return {"pipeline_ms_per_scene": sum(walls) / 2, "parts_ms": {k_: round(v_, 3) for k_, v_ in parts.items()}, "substeps": substeps,
+            "finite": bool(torch.isfinite(solver.get_field("x")).all()), "out_of_bounds": solver.out_of_bounds, "particles_per_material_id": mats,
+            "workload": f"{D}^3 x {C} feature grid -> SegmentationUNet + RegressionUNet -> field transfer onto {args.particles} particles -> "
+                        f"{substeps} substeps (n_grid {args.n_grid}, dt {sc['dt']:g}); device-resident, 1 scene"}
 
 
 def bench_field_transfer(args, device):
@@ -634,11 +693,13 @@ def cpu_baselines(args):
                 "sample": f"{n} particles, n_grid {n_grid}, {steps} substeps ({dt:.1f} s), {what}"}
 
     n = min(args.particles, 100_000)
-    cores = os.cpu_count() or 1
+    cores = torch.get_num_threads()
+    os.environ["OMP_NUM_THREADS"] = str(cores)     # the OpenMP build of the C oracle: one thread per core torch uses, like the U-Net leg
     # the stated multi-core baseline: the C oracle (pinned to the reference's kernels, tests/test_mpm_ref_golden.py) with
-    # OpenMP over particles / grid nodes and atomic P2G adds, on every host core; the scalar build on one core beside it
+    # OpenMP over particles / grid nodes and an atomic-free P2G (particles sorted into 4^3-cell tiles, 8 colours of tiles one
+    # after the other: oracle/mpm_oracle.c), on the host's cores; the scalar build on one core beside it
     out["mpm"] = timed(lambda n_, sc: OracleMPM(n_, sc["n_grid"], sc["grid_lim"], "f32_omp"), n, args.n_grid, 200,
-                       f"oracle/mpm_oracle.c float32, OpenMP on {cores} host threads", cores)
+                       f"oracle/mpm_oracle.c float32, OpenMP on {cores} host threads (atomic-free coloured P2G)", cores)
     out["mpm"]["single_core"] = timed(lambda n_, sc: OracleMPM(n_, sc["n_grid"], sc["grid_lim"], "f32"), n, args.n_grid, 20,
                                       "oracle/mpm_oracle.c float32, scalar C", 1)
     if not (args.no_mpm or args.no_mpm_large):
@@ -879,18 +940,31 @@ def compact_line(d, detail_path=None):
         line["mpm_1m_in_motion_frac_touched"] = _r(mv["frac_touched_cells"])
     m = d.get("mpm") or {}
     line["mpm_frac"] = line.get("mpm_frac_dense")
+    if m.get("floor_us"):
+        # single 100 k scene: launch-latency bound -- the substep against the empty-scene substep of the same two launches
+        line["mpm_floor_us"], line["mpm_frac_of_floor"] = _r(m["floor_us"]), _r(m["frac_of_floor"])
     if m.get("p2g2p_loop"):
         line["p2g2p_loop_vs_run"] = _r(m["p2g2p_loop"]["vs_run"])
         line["p2g2p_loop_us_per_substep"] = _r(m["p2g2p_loop"]["us_per_substep"])
     if m.get("multi_scene"):
-        line["mpm_3_scenes_particle_steps_per_s"] = _r(m["multi_scene"]["value"])
-        if m["multi_scene"].get("six_scenes"):
-            line["mpm_6_scenes_particle_steps_per_s"] = _r(m["multi_scene"]["six_scenes"]["value"])
+        ms = m["multi_scene"]
+        # the MPM headline of the BATCH configuration (BASELINE configs[3]): >= 3 scenes per GPU, where the launch latency of one
+        # scene is hidden behind the others
+        line["mpm_batch"] = {"scenes_per_gpu": ms["scenes"], "particle_steps_per_s": _r(ms["value"]), "frac_dense": _r(ms.get("frac_dense_grid")),
+                             "frac_touched": _r(ms.get("frac_touched_cells"))}
+        line["mpm_3_scenes_particle_steps_per_s"] = _r(ms["value"])
+        if ms.get("six_scenes"):
+            line["mpm_6_scenes_particle_steps_per_s"] = _r(ms["six_scenes"]["value"])
+            line["mpm_6_scenes_frac_dense"] = _r(ms["six_scenes"].get("frac_dense_grid"))
     if m.get("other_scatter_mode"):
         line["mpm_exact_scatter_us_per_substep"] = _r(m["other_scatter_mode"]["us_per_substep"])
     sh = d.get("shipped_shape_64x768") or {}
     if sh.get("fused_first_projector_conv"):
         line["shipped_64x768_ms_per_scene"] = _r(sh["fused_first_projector_conv"]["ms_per_scene"])
+    if d.get("pipeline_configs2"):
+        pp = d["pipeline_configs2"]
+        line["pipeline_ms_per_scene"] = _r(pp["pipeline_ms_per_scene"])
+        line["pipeline_parts_ms"] = {k.replace("_ms", ""): _r(v) for k, v in pp["parts_ms"].items() if k != "total_ms"}
     if d.get("field_to_particles"):
         line["field_to_particles_ms"] = _r(d["field_to_particles"]["ms"])
     cb = d.get("cpu_baseline")
@@ -934,7 +1008,7 @@ def main():
         # BASELINE configs[4]'s per-GPU MPM workload (1M particles, n_grid 120, 2000 substeps): where the HBM roofline fraction is meaningful
         m_large = None if (args.no_mpm or args.no_mpm_large) else M(args, rank, world, device, 1_000_000, 120, args.mpm_large_substeps, "1m")
         other_bits = {64: 32, 32: 64}
-        m_alt = m_large_alt = m_multi = ft = shipped = u256 = cpu = None
+        m_alt = m_large_alt = m_multi = ft = shipped = u256 = cpu = pipe = None
         if rank == 0 and world == 1 and not args.no_mpm and not dry:
             # the other scatter mode beside the default (exact 64-bit <-> packed 32-bit pairs), and the multi-scene leg
             m_alt = bench_mpm(args, rank, world, device, args.particles, args.n_grid, args.mpm_substeps, "100k",
@@ -977,8 +1051,17 @@ def main():
             m_multi = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 3)
             six = bench_mpm_multi_scene(args, device, args.particles, args.n_grid, args.mpm_substeps, 6)
             m_multi["six_scenes"] = {k: six[k] for k in ("value", "unit", "scenes", "us_per_substep_per_scene", "finite")}
+            # the batch configuration (BASELINE configs[3]: several scenes per job) as roofline fractions: the bytes of one scene's
+            # substep x the scenes, over the time the GPU needs for one substep of all of them
+            for mm in (m_multi, m_multi["six_scenes"]):
+                t = mm["us_per_substep_per_scene"] * 1e-6         # (wall time of one substep of ALL scenes of the leg)
+                mm["frac_dense_grid"] = mm["scenes"] * m["substep_bytes_dense"] / t / 1e9 / PEAK_HBM_GBPS
+                mm["frac_touched_cells"] = mm["scenes"] * m["substep_bytes_touched"] / t / 1e9 / PEAK_HBM_GBPS
+            m["floor_us"] = bench_mpm_floor(device, args.n_grid)
+            m["frac_of_floor"] = m["floor_us"] / m["us_per_substep"]
         if not dry:
             ft = bench_field_transfer(args, device) if (rank == 0 and not args.no_mpm) else None
+            pipe = bench_pipeline(args, device, args.mpm_substeps) if (rank == 0 and world == 1 and not args.no_mpm and not args.no_pipeline) else None
             shipped = bench_shipped_shape(args, device) if (rank == 0 and world == 1 and not args.no_shipped_shape) else None
             # BASELINE configs[4]'s per-GPU U-Net workload: 256^3 x 128 (217 TFLOP per scene, ~60 GiB of workspace)
             if rank == 0 and world == 1 and not args.no_unet_256 and u["precision"] == "f16x3" and args.grid == 128:
@@ -992,6 +1075,8 @@ def main():
     if rank == 0:
         detail = assemble_detail(args, world, u, u32, m, m_large, m_alt, m_large_alt, m_multi, ft, shipped, u256, cpu,
                                  threads_per_rank=threads, dry=dry)
+        if pipe is not None:
+            detail["pipeline_configs2"] = pipe
         path = None
         try:       # gpurun_out/ travels back from the GPU box; the session scripts copy the file into profiles/
             os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)

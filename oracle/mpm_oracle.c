@@ -720,42 +720,40 @@ static int stencil_inside(const MPM *s, const int *base) {
     return 1;
 }
 
-/* p2g_apic_with_stress, mpm_utils.py:338-394 */
-void mpm_p2g(MPM *s, double dt_d) {
-    real dt = P_(dt_d);
-    OMP_FOR
-    for (int p = 0; p < s->n; ++p) {
-        if (s->selection[p] != 0) continue;
-        const real *stress = s->stress + 9 * p;
-        int base[3]; real fx[3], w[3][3], dw[3][3];
-        stencil(s, s->x + 3 * p, base, fx, w, dw);
-        if (!stencil_inside(s, base)) { /* reference: no bounds check (UB) */
-            OMP_ATOMIC
-            s->oob++;
-            continue;
-        }
-        /* C' and -vol*stress do not depend on (i,j,k); the reference recomputes them per node
-         * (:372-381) with identical operands, so hoisting is value-preserving. */
-        real C[9], nvs[9];
-        const real *Cp = s->C + 9 * p;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b)
-                C[3 * a + b] = (R_(1.0) - s->rpic_damping) * Cp[3 * a + b] +
-                               s->rpic_damping / R_(2.0) * (Cp[3 * a + b] - Cp[3 * b + a]);
-        if (s->rpic_damping < R_(-0.001)) memset(C, 0, sizeof C);
-        for (int a = 0; a < 9; ++a) nvs[a] = -s->vol[p] * stress[a];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j)
-                for (int k = 0; k < 3; ++k) {
-                    real dpos[3] = {((real)i - fx[0]) * s->dx, ((real)j - fx[1]) * s->dx, ((real)k - fx[2]) * s->dx};
-                    real weight = w[0][i] * w[1][j] * w[2][k];
-                    real dweight[3] = {dw[0][i] * w[1][j] * w[2][k] * s->inv_dx, w[0][i] * dw[1][j] * w[2][k] * s->inv_dx,
-                                       w[0][i] * w[1][j] * dw[2][k] * s->inv_dx}; /* compute_dweight :303-312 */
-                    real ef[3], Cd[3];
-                    m_vec(nvs, dweight, ef);
-                    m_vec(C, dpos, Cd);
-                    real wm = weight * s->mass[p];
-                    size_t gi = GI(s, base[0] + i, base[1] + j, base[2] + k);
+/* p2g_apic_with_stress, mpm_utils.py:338-394: one particle.  `atomic`: the adds are `omp atomic` (threads may share nodes) */
+static inline void p2g_particle(MPM *s, int p, real dt, int atomic) {
+    if (s->selection[p] != 0) return;
+    const real *stress = s->stress + 9 * p;
+    int base[3]; real fx[3], w[3][3], dw[3][3];
+    stencil(s, s->x + 3 * p, base, fx, w, dw);
+    if (!stencil_inside(s, base)) { /* reference: no bounds check (UB) */
+        OMP_ATOMIC
+        s->oob++;
+        return;
+    }
+    /* C' and -vol*stress do not depend on (i,j,k); the reference recomputes them per node
+     * (:372-381) with identical operands, so hoisting is value-preserving. */
+    real C[9], nvs[9];
+    const real *Cp = s->C + 9 * p;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            C[3 * a + b] = (R_(1.0) - s->rpic_damping) * Cp[3 * a + b] +
+                           s->rpic_damping / R_(2.0) * (Cp[3 * a + b] - Cp[3 * b + a]);
+    if (s->rpic_damping < R_(-0.001)) memset(C, 0, sizeof C);
+    for (int a = 0; a < 9; ++a) nvs[a] = -s->vol[p] * stress[a];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) {
+                real dpos[3] = {((real)i - fx[0]) * s->dx, ((real)j - fx[1]) * s->dx, ((real)k - fx[2]) * s->dx};
+                real weight = w[0][i] * w[1][j] * w[2][k];
+                real dweight[3] = {dw[0][i] * w[1][j] * w[2][k] * s->inv_dx, w[0][i] * dw[1][j] * w[2][k] * s->inv_dx,
+                                   w[0][i] * w[1][j] * dw[2][k] * s->inv_dx}; /* compute_dweight :303-312 */
+                real ef[3], Cd[3];
+                m_vec(nvs, dweight, ef);
+                m_vec(C, dpos, Cd);
+                real wm = weight * s->mass[p];
+                size_t gi = GI(s, base[0] + i, base[1] + j, base[2] + k);
+                if (atomic) {
                     for (int d = 0; d < 3; ++d) {
                         real add = wm * (s->v[3 * p + d] + Cd[d]) + dt * ef[d];
                         OMP_ATOMIC
@@ -763,9 +761,55 @@ void mpm_p2g(MPM *s, double dt_d) {
                     }
                     OMP_ATOMIC
                     s->grid_m[gi] += wm;                           /* :394 */
+                } else {
+                    for (int d = 0; d < 3; ++d) s->grid_v_in[3 * gi + d] += wm * (s->v[3 * p + d] + Cd[d]) + dt * ef[d];
+                    s->grid_m[gi] += wm;
                 }
+            }
+}
+
+#ifdef _OPENMP
+/* The multi-core build (bench.py's cpu_baseline only).  Atomic float adds from 256 threads into one grid scale to ~2 cores
+ * (every add moves a cache line between cores), so this build scatters WITHOUT atomics: the particles are counting-sorted into
+ * 4^3-cell tiles (the base cell of the stencil decides), the tiles are coloured by the parity of their three indices, and the
+ * eight colours run one after the other -- two tiles of one colour are at least 8 cells apart on some axis while a stencil
+ * reaches 2 cells beyond its base, so the threads of a colour never touch the same node.  Same arithmetic per particle; the
+ * order of the sums differs from the serial builds (which the tests use). */
+static int *g_tile_of = NULL, *g_tile_start = NULL, *g_tile_fill = NULL, *g_sorted = NULL;
+static int g_cap_n = 0, g_cap_t = 0;
+void mpm_p2g(MPM *s, double dt_d) {
+    real dt = P_(dt_d);
+    const int nt = (s->ng + 3) / 4, T = nt * nt * nt, n = s->n;
+    if (n > g_cap_n) { free(g_tile_of); free(g_sorted); g_tile_of = malloc(sizeof(int) * n); g_sorted = malloc(sizeof(int) * n); g_cap_n = n; }
+    if (T + 1 > g_cap_t) { free(g_tile_start); free(g_tile_fill); g_tile_start = malloc(sizeof(int) * (T + 1)); g_tile_fill = malloc(sizeof(int) * (T + 1)); g_cap_t = T + 1; }
+    OMP_FOR
+    for (int p = 0; p < n; ++p) {
+        int base[3]; real fx[3], w[3][3], dw[3][3];
+        stencil(s, s->x + 3 * p, base, fx, w, dw);
+        int t[3];
+        for (int d = 0; d < 3; ++d) { int b = base[d] < 0 ? 0 : (base[d] >= s->ng ? s->ng - 1 : base[d]); t[d] = b / 4; }
+        g_tile_of[p] = (t[0] * nt + t[1]) * nt + t[2];
+    }
+    memset(g_tile_start, 0, sizeof(int) * (T + 1));
+    for (int p = 0; p < n; ++p) g_tile_start[g_tile_of[p] + 1]++;
+    for (int t = 0; t < T; ++t) g_tile_start[t + 1] += g_tile_start[t];
+    memcpy(g_tile_fill, g_tile_start, sizeof(int) * (T + 1));
+    for (int p = 0; p < n; ++p) g_sorted[g_tile_fill[g_tile_of[p]]++] = p;
+    for (int colour = 0; colour < 8; ++colour) {
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (int t = 0; t < T; ++t) {
+            const int tz = t % nt, ty = (t / nt) % nt, tx = t / (nt * nt);
+            if ((((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1)) != colour) continue;
+            for (int q = g_tile_start[t]; q < g_tile_start[t + 1]; ++q) p2g_particle(s, g_sorted[q], dt, 0);
+        }
     }
 }
+#else
+void mpm_p2g(MPM *s, double dt_d) {
+    real dt = P_(dt_d);
+    for (int p = 0; p < s->n; ++p) p2g_particle(s, p, dt, 1);
+}
+#endif
 
 /* grid_normalization_and_gravity, mpm_utils.py:398-409 */
 void mpm_grid_update(MPM *s, double dt_d) {

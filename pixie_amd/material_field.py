@@ -74,13 +74,14 @@ def field_to_particles(pred: torch.Tensor, mask: torch.Tensor, min_bounds: Seque
 
 def apply_material_field_to_solver(mpm_solver, pred: torch.Tensor, mask: torch.Tensor, min_bounds, max_bounds,
                                    particle_pos_field_frame: torch.Tensor, k_smoothing_neighbors: int = 10,
-                                   nn_distance_threshold: float = 0.1, weighted_assignment: bool = False):
+                                   nn_distance_threshold: float = 0.1, weighted_assignment: bool = False,
+                                   ranges: Optional[Dict[str, float]] = None):
     """The device-resident equivalent of apply_material_field_to_simulation's property hand-off
     (material_field.py:303-363, minus the ground / stationary-cluster boundary conditions, which stay with the
     caller): K-NN transfer, the reference's 10 % too-far assertion (:275), then one array upload per property instead of
     one apply_additional_params launch per particle.  Returns the per-particle confidence."""
     res = field_to_particles(pred, mask, min_bounds, max_bounds, particle_pos_field_frame, k_smoothing_neighbors,
-                             nn_distance_threshold, weighted_assignment)
+                             nn_distance_threshold, weighted_assignment, ranges=ranges)   # ranges: the dataset's normalization_ranges.yaml (default: the shipped one)
     n = particle_pos_field_frame.shape[0]
     n_far = int(res["n_too_far"])
     assert n_far <= 0.1 * n, (f"[CRITICAL] More than 10% of particles are too far from nearest neighbor. "

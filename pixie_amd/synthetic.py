@@ -160,6 +160,33 @@ def apply_scene(solver, scene, per_particle: bool = True):
     solver.finalize_mu_lam()
 
 
+# --------------------------------------------------------------------------- the two halves together (BASELINE configs[2])
+# Normalisation ranges of the SYNTHETIC scene, in the format of normalization_stats/normalization_ranges.yaml (log10 for density and
+# E): the material ranges SURVEY 8d prescribes for the MPM scene (E = 10^[5, 6.3] Pa, nu in [0.2, 0.4], rho = 10^[2.3, 3.3]), so that
+# whatever the randomly initialised networks predict is un-scaled into a CFL-safe material (the un-scaling clamps to [-1, 1]); the
+# shipped ranges reach E = 10^10.9 Pa, for which dt = 1e-4 is unstable ("smoke test only")
+PIPELINE_RANGES = {"density_min": 2.3, "density_max": 3.3, "E_min": 5.0, "E_max": 6.3, "nu_min": 0.2, "nu_max": 0.4}
+
+
+def pipeline_scene(D: int = 128, C: int = 64, n_particles: int = 100_000, seed: int = 0, n_grid: int = 50):
+    """BASELINE configs[2] as ONE scene: the 128^3 x 64 feature grid of configs[1] with its occupancy ball (radius 0.35 D), and the
+    100 k-particle ball of the MPM configuration inside the occupied region.  Field frame: [-1, 1]^3 over the grid; simulation
+    frame: the ball of radius 0.5 at (1, 1, 1) in [0, 2]^3 -- field = (sim - 1) * 1.3 puts the particle ball (radius 0.65 in field
+    units) inside the occupied voxels (radius 0.7).  Materials come from the networks (un-scaled with PIPELINE_RANGES); the solver
+    scalars are the jelly defaults of the tree scenario without its impulse / slab (the predicted ids include every material)."""
+    sc = mpm_ball_scene(n_particles, seed=seed, n_grid=n_grid, scenario="ball")
+    g = (np.arange(D, dtype=np.float32) - (D - 1) / 2.0) / (D / 2.0)
+    rr = np.sqrt(g[:, None, None] ** 2 + g[None, :, None] ** 2 + g[None, None, :] ** 2)
+    sc["mask"] = (rr < 0.7).astype(np.float32)
+    sc["feat"] = feature_grid(D, C, seed=100 + seed)
+    sc["field_scale"] = 1.3
+    sc["min_bounds"], sc["max_bounds"] = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]
+    sc["params"] = dict(material="jelly", g=[0.0, 0.0, -9.8], E=2e6, nu=0.4, density=200.0, yield_stress=2e4, hardening=1, xi=0.1,
+                        softening=0.1, friction_angle=30.0, grid_v_damping_scale=0.9999)
+    sc["ranges"] = dict(PIPELINE_RANGES)
+    return sc
+
+
 # --------------------------------------------------------------------------- U-Net
 def feature_grid(D: int, C: int = 64, seed: int = 0, occupancy: bool = False) -> np.ndarray:
     """(1,C,D,D,D) float32 feature grid; `occupancy` masks to a ball of radius 0.35 D and

@@ -12,6 +12,9 @@ CUT with `ast` (their files cannot be imported whole: hydra / omegaconf / wandb 
     ref_unet_driver.py   create_models, process_batch, save_predictions (WG/trainer/inference_combined.py:81-217);
                          masked_mean, compute_accuracy, load_checkpoint (pixie/training_utils.py); InferenceMetrics
                          (pixie/metrics.py:105-153); MaterialVoxelDataset (WG/data_utils/my_data.py:19-224)
+    ref_sharded_inference.py   run_inference_on_gpu, load_test_dataset (WG/trainer/inference_combined.py:48-79,229-288);
+                         load_normalization_ranges (pixie/training_utils.py:21-48); generate_metrics_report, save_metrics_file
+                         (pixie/metrics.py); its header's ddp_setup takes the backend from the runner (the reference hard-codes "nccl")
     ref_map_pred.py      unscale_prediction, get_mat_id, map_pred_to_ply (pixie/voxel/map_pred_to_coords.py:41-75, 122-283)
     ref_gs_main.py       load_point_cloud (gs_simulation.py:108-202) and the statements of gs_simulation.py's __main__ block
                          that set up and drive the solver (:483-502, :531, :558-561, the frame loop :573-634 with the
@@ -130,6 +133,27 @@ def main():
         cut(f"{WG}/trainer/inference_combined.py", ["create_models", "process_batch", "save_predictions"]),
     ])
     open(os.path.join(OUT, "ref_unet_driver.py"), "w").write(unet + "\n")
+
+    # the multi-process entry (WG/trainer/inference_combined.py:229-288) with what it calls.  The header's ddp_setup is the ONE edit
+    # beyond the documented import swap: the reference's (pixie/training_utils.py:50-55) hard-codes backend "nccl" and
+    # torch.cuda.set_device(rank), which cannot form two ranks on a one-GPU box (or on CPU); the runner passes backend / port in.
+    sharded = "\n\n\n".join([
+        '"""Cut from the reference by scripts/reference_drivers/make_scratch.py -- see there.  The sharded inference loop."""',
+        "import logging\nimport math\nimport os\nimport sys\nfrom collections import defaultdict\nfrom pathlib import Path\n\nimport numpy as np\nimport torch\n"
+        "import torch.distributed as dist\nimport yaml\nfrom torch.utils.data import DataLoader, Subset\nfrom torch.utils.data.distributed import DistributedSampler\n\n"
+        "from ref_unet_driver import InferenceMetrics, MaterialVoxelDataset, create_models, load_checkpoint, process_batch\n\n"
+        "DictConfig = object\nDDP_BACKEND, DDP_PORT = 'gloo', '12355'\n\n\n"
+        "def set_logger():\n    logging.basicConfig(level=logging.INFO)\n\n\n"
+        "def tqdm(it, **kw):\n    return it\n\n\n"
+        "def save_json(obj, path):\n    import json\n    json.dump(obj, open(path, 'w'), indent=2, default=float)\n\n\n"
+        "def ddp_setup(rank, world_size):      # pixie/training_utils.py:50-55 with the backend / port of the runner (see make_scratch.py)\n"
+        "    os.environ['MASTER_ADDR'] = '127.0.0.1'\n    os.environ['MASTER_PORT'] = DDP_PORT\n"
+        "    dist.init_process_group(DDP_BACKEND, rank=rank, world_size=world_size)\n    torch.cuda.set_device(rank)",
+        cut(f"{REF}/pixie/training_utils.py", ["load_normalization_ranges"]),
+        cut(f"{REF}/pixie/metrics.py", ["save_metrics_file", "generate_metrics_report"]),
+        cut(f"{WG}/trainer/inference_combined.py", ["load_test_dataset", "run_inference_on_gpu"]),
+    ])
+    open(os.path.join(OUT, "ref_sharded_inference.py"), "w").write(sharded + "\n")
 
     mp = "\n\n\n".join([
         '"""Cut from pixie/voxel/map_pred_to_coords.py by scripts/reference_drivers/make_scratch.py -- see there."""',

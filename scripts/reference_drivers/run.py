@@ -16,6 +16,8 @@ container): the only edits are the import swaps INTEGRATION.md section 1 documen
                      same class surface: per-frame positions / covariances handed to the rasteriser must agree.
                      Also decides the `live_exports` default: does the driver ever read an exported tensor it held
                      across p2g2p calls without re-exporting?
+  E. sharded U-Net program  run_inference_on_gpu (inference_combined.py:229-288) verbatim as `--world` processes (mp.spawn, gloo):
+                     ddp_setup, DistributedSampler, DataLoader, gather_all_metrics, generate_metrics_report; against a 1-process run.
   D. particle pre-pass  gs_simulation.py:413-482 verbatim (rotation, transform2origin, shift2center111, fill_particles,
                      get_particle_volume, init_filled_particles) with the reference's custom_sand_config.json -- the config
                      that sets `"smooth": true` -- on pixie_amd.particle_filling; the result is checked against the chain
@@ -373,6 +375,89 @@ def part_d(n_gaussians):
     return L
 
 
+# ============================================================================================ E. the sharded U-Net program
+class NCfg(dict):
+    """Nested attribute-access config that can be assigned to (load_normalization_ranges writes cfg.training.E_min = ...)."""
+    def __init__(self, d=()):
+        super().__init__()
+        for k, v in dict(d).items():
+            self[k] = NCfg(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def get(self, k, d=None):
+        return self[k] if k in self else d
+
+
+def _part_e_worker(rank, world, cfg_dict, seg_ckpt, cont_ckpt, out_dir, port):
+    """What mp.spawn runs per rank in the reference (main_worker -> run_inference_on_gpu, inference_combined.py:291-353)."""
+    import ref_sharded_inference as S
+    import ref_unet_driver as R
+    R.get_obj_class_for_id = lambda obj_id, cfg: "tree"
+    R.load_json = lambda p: json.load(open(p))
+    S.DDP_BACKEND, S.DDP_PORT = "gloo", str(port)
+    S.run_inference_on_gpu(rank, world, NCfg(cfg_dict), seg_ckpt, cont_ckpt, None, out_dir, print_table=False)   # verbatim :229-288
+
+
+def part_e(root, D, C, world):
+    """run_inference_on_gpu (inference_combined.py:229-288) verbatim -- ddp_setup, load_normalization_ranges, load_test_dataset,
+    DistributedSampler(shuffle=False), DataLoader(pin_memory), create_models, load_checkpoint, process_batch per batch,
+    InferenceMetrics.gather_all_metrics (dist.gather_object), generate_metrics_report on rank 0 -- as `world` processes started with
+    torch.multiprocessing.spawn, on gloo (the reference's "nccl" cannot form two ranks on this box's single GPU; its
+    rank == device-ordinal convention needs `world` visible devices: the session script exposes the GPU twice when it can).
+    Checks: every object's four files exist exactly once, they equal a single-process run over the same objects bit for bit,
+    rank 0's report lists every object."""
+    import torch.multiprocessing as mp
+    from pixie_amd.unet_plan import UNetConfig, synthetic_state_dict
+    cfg = make_cfg(root, D, C)
+    cfg["training"]["inference"] = dict(batch_size=1, data_worker=0, use_saved_test_split=False)
+    cfg["training"]["training"]["train_size"] = 0.0
+    obj_ids = [f"sharded_{k}" for k in range(4)]
+    for d in (cfg.paths.render_outputs_dir,):
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    synth_objects(cfg, D, C, obj_ids)
+    os.makedirs(cfg.paths.normalization_stats_dir, exist_ok=True)
+    import yaml
+    yaml.safe_dump({"density_p1": 1.70319, "density_p99": 3.87143, "E_p1": 3.01830, "E_p99": 10.88168, "nu_p1": 0.210276, "nu_p99": 0.449269},
+                   open(os.path.join(cfg.paths.normalization_stats_dir, "normalization_ranges.yaml"), "w"))
+    ckpts = []
+    for tag, oc, seed in (("seg", 8, 0), ("cont", 3, 1000)):
+        sd = synthetic_state_dict(UNetConfig(feature_channels=C, grid_size=D, out_channels=oc), seed)
+        path = os.path.join(root, f"{tag}_sharded_epoch_3.pth")
+        torch.save({"epoch": 3, "model_state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "optimizer_state_dict": {}, "scheduler_state_dict": None}, path)
+        ckpts.append(path)
+    import socket
+    outs = {}
+    for w in sorted({1, world}):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        out_dir = os.path.join(root, f"sharded_results_w{w}")
+        t0 = time.perf_counter()
+        mp.spawn(_part_e_worker, args=(w, json.loads(json.dumps(cfg)), ckpts[0], ckpts[1], out_dir, port), nprocs=w, join=True)
+        outs[w] = out_dir
+        files = sorted(os.listdir(out_dir))
+        say(f"E. run_inference_on_gpu verbatim, world_size {w} (mp.spawn, gloo, {torch.cuda.device_count()} visible device(s)): {time.perf_counter() - t0:.1f} s; {files}")
+        ev = json.load(open(os.path.join(out_dir, "evaluated_obj_ids.json")))
+        assert ev == obj_ids, ev
+        assert any(f.startswith("metrics") or f.endswith("metrics.json") for f in files) or len(files) >= len(obj_ids) + 2, files
+        for oid in obj_ids:
+            assert sorted(os.listdir(os.path.join(out_dir, oid))) == ["sample_0_gt.npy", "sample_0_info.npy", "sample_0_mask.npy", "sample_0_pred.npy"], oid
+    if world > 1:
+        for oid in obj_ids:
+            for f in ("sample_0_pred.npy", "sample_0_gt.npy", "sample_0_mask.npy"):
+                a, b = np.load(os.path.join(outs[1], oid, f)), np.load(os.path.join(outs[world], oid, f))
+                assert np.array_equal(a, b), (oid, f)
+        say(f"   world_size {world} == world_size 1: the {len(obj_ids)} objects' pred / gt / mask files are bit-identical; rank 0's report lists all of them")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=64)        # map_pred_to_ply asserts a 64^3 mask (map_pred_to_coords.py:182)
@@ -381,6 +466,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--gaussians", type=int, default=20000)
     ap.add_argument("--only", default="abcd")
+    ap.add_argument("--world", type=int, default=2, help="part e: ranks of the sharded U-Net program (needs that many visible devices)")
     a = ap.parse_args()
     assert torch.cuda.is_available(), "needs the GPU box"
     root = tempfile.mkdtemp(prefix="pixie_ref_drivers_")
@@ -391,6 +477,8 @@ def main():
         part_c(root, ply, a.particles, a.frames)
     if "d" in a.only:
         part_d(a.gaussians)
+    if "e" in a.only:
+        part_e(root, min(a.grid, 32), a.channels, min(a.world, torch.cuda.device_count()))
     say("ALL CHECKS PASSED")
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     open(os.path.join(REPO, "gpurun_out", "reference_drivers.log"), "w").write("\n".join(LOG) + "\n")
