@@ -252,6 +252,12 @@ int pixie_voxel_grid_to_ncdhw(const void* d_feat_dhwc_f16, int d, int h, int w, 
 int pixie_projector_conv0(const void* d_feat_dhwc_f16, int64_t voxels, int channels, int n_networks, const void* const* d_w16,
                           const float* const* d_bias, float* const* d_out, int c_out, void* stream);
 
+/* The field exchange between ranks (the reference writes a 44 B/voxel (11, D, D, D) float file per scene and has no
+ * exchange): n_scenes x (3, V) float32 continuous channels + n_scenes x V int32 class ids -> the 13 B/voxel wire buffer
+ * [3 n V float32 | n V uint8 | zero pad to a multiple of 16 B] that ONE all-gather moves (pixie_amd/distributed.py).  One launch. */
+int pixie_pack_fields(const float* d_cont, const int32_t* d_seg_pred, int64_t n_scenes, int64_t spatial, void* d_wire, int64_t wire_bytes,
+                      void* stream);
+
 /* process_batch/save_predictions (WG/trainer/inference_combined.py:124-126,186-195):
  * combined[0:3] = cont_pred; combined[3+k] = (argmax_c logits == k), ties -> lowest index. */
 int pixie_combine_predictions(const float* d_logits, int num_classes, const float* d_cont, int64_t spatial,

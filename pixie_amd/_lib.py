@@ -101,6 +101,7 @@ SIGNATURES = {
     "pixie_mpm_export_R": (_I, [_VP, _VP, _VP]),
     "pixie_mpm_export_frame": (_I, [_VP, _I, _D3, _D, _D3, C.POINTER(C.c_double), _VP, _VP, _VP]),
     "pixie_mpm_out_of_bounds": (_I, [_VP, C.POINTER(_I64), _VP]),
+    "pixie_pack_fields": (_I, [_VP, _VP, _I64, _I64, _VP, _I64, _VP]),
     "pixie_conv_cout_padded": (_I, [_I]),
     "pixie_conv_pack_weights": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "pixie_conv_packed16_bytes": (_I64, [_I, _I, _I]),

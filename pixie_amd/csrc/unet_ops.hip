@@ -8,6 +8,8 @@
 //  combine                   argmax + one-hot + concat of inference_combined.py:124-126,186-195.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../../include/pixie_hip.h"
 #include "common.h"
 
@@ -296,6 +298,25 @@ __global__ void combine_ids_kernel(const int* __restrict__ seg, int ncls, const 
     for (int c = 0; c < ncls; ++c) combined[(size_t)(3 + c) * spatial + i] = (c == id) ? 1.0f : 0.0f;
 }
 
+// The field exchange's wire buffer (pixie_amd/distributed.py): [n * 3 * V float32 | n * V uint8 class ids | pad to 16 B], from
+// the networks' outputs in ONE pass: thread t moves float4 number t of the continuous block (3 V / 4 per scene ... the block is
+// contiguous over the n scenes) and packs class ids 4 t .. 4 t + 3 into one 32-bit store.  HBM-bound: 16 B read, 13 B written per voxel.
+__global__ __launch_bounds__(256) void pack_fields_kernel(const float* __restrict__ cont, const int* __restrict__ seg, long n_float, long n_vox,
+                                                          unsigned char* __restrict__ wire, long wire_bytes) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float4* wf = reinterpret_cast<float4*>(wire);
+    if (4 * t + 3 < n_float) wf[t] = reinterpret_cast<const float4*>(cont)[t];
+    else for (long i = 4 * t; i < n_float; ++i) reinterpret_cast<float*>(wire)[i] = cont[i];
+    unsigned char* wb = wire + 4 * n_float;      // (n_float = 3 n V: a multiple of 4 bytes, so 32-bit stores stay aligned when V is)
+    if (4 * t + 3 < n_vox && (n_vox & 3) == 0) {
+        const int4 q = reinterpret_cast<const int4*>(seg)[t];
+        reinterpret_cast<unsigned*>(wb)[t] = (unsigned)(q.x & 0xff) | ((unsigned)(q.y & 0xff) << 8) | ((unsigned)(q.z & 0xff) << 16) | ((unsigned)(q.w & 0xff) << 24);
+    } else {
+        for (long i = 4 * t; i < n_vox && i < 4 * t + 4; ++i) wb[i] = (unsigned char)seg[i];
+    }
+    if (t == 0) for (long i = 4 * n_float + n_vox; i < wire_bytes; ++i) wire[i] = 0;     // the <= 15 pad bytes
+}
+
 template <int C>
 static int launch_attention(const float* qkv, float* out, int T, hipStream_t st) {
     const size_t merge = ((size_t)ATT_WAVES * C * ATT_BQ + 2 * ATT_WAVES * ATT_BQ) * sizeof(float);
@@ -432,6 +453,19 @@ extern "C" int pixie_combine_class_ids(const int32_t* d_seg_pred, int num_classe
     PX_REQUIRE(d_seg_pred && d_cont && d_combined && num_classes > 0 && spatial > 0, "pixie_combine_class_ids: bad arguments");
     hipLaunchKernelGGL(combine_ids_kernel, dim3(cdiv(spatial, 256)), dim3(256), 0, as_stream(stream), d_seg_pred, num_classes, d_cont,
                        (long)spatial, d_combined);
+    PX_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int pixie_pack_fields(const float* d_cont, const int32_t* d_seg_pred, int64_t n_scenes, int64_t spatial, void* d_wire, int64_t wire_bytes,
+                                 void* stream) {
+    const int64_t n_float = 3 * n_scenes * spatial, n_vox = n_scenes * spatial;
+    PX_REQUIRE(d_cont && d_seg_pred && d_wire && n_scenes > 0 && spatial > 0, "pixie_pack_fields: bad arguments");
+    PX_REQUIRE(wire_bytes >= 4 * n_float + n_vox && wire_bytes < 4 * n_float + n_vox + 16, "pixie_pack_fields: wire buffer of %lld bytes for %lld scenes x %lld voxels",
+               (long long)wire_bytes, (long long)n_scenes, (long long)spatial);
+    const int64_t threads = (std::max(n_float, n_vox) + 3) / 4;
+    hipLaunchKernelGGL(pack_fields_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, as_stream(stream), d_cont, d_seg_pred, (long)n_float, (long)n_vox,
+                       (unsigned char*)d_wire, (long)wire_bytes);
     PX_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -55,11 +55,21 @@ def wire_bytes(n_local: int, voxels: int) -> int:
 
 
 def pack_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor) -> torch.Tensor:
-    """(n, 3, D, H, W) fp32 + (n, D, H, W) integer class ids -> ONE uint8 wire buffer: [n * 3 * V floats | n * V bytes | pad]."""
+    """(n, 3, D, H, W) fp32 + (n, D, H, W) integer class ids -> ONE uint8 wire buffer: [n * 3 * V floats | n * V bytes | pad].
+    Device tensors: one launch of pixie_pack_fields (csrc/unet_ops.hip; three torch copy kernels until round 4).  Host tensors --
+    the gloo tests and `bench.py --dry-run`, which exercise the N-rank control path without a device -- are packed with torch."""
     n, vox = cont_pred.shape[0], seg_pred[0].numel() if seg_pred.shape[0] else 0
     buf = torch.empty(wire_bytes(n, vox), dtype=torch.uint8, device=cont_pred.device)
+    if cont_pred.is_cuda and n * vox > 0:
+        import ctypes as C
+        from . import _lib
+        cont = cont_pred.detach().to(torch.float32).contiguous()
+        seg = seg_pred.to(torch.int32).contiguous()
+        _lib.check(_lib.load().pixie_pack_fields(C.c_void_p(cont.data_ptr()), C.c_void_p(seg.data_ptr()), n, vox, C.c_void_p(buf.data_ptr()),
+                                                 buf.numel(), _lib.current_stream_ptr()), "pixie_pack_fields")
+        return buf
     nf = 12 * n * vox
-    buf[:nf].view(torch.float32).copy_(cont_pred.reshape(-1))          # dtype conversion (if any) rides in the copy kernel
+    buf[:nf].view(torch.float32).copy_(cont_pred.reshape(-1))          # dtype conversion (if any) rides in the copy
     buf[nf:nf + n * vox].copy_(seg_pred.reshape(-1))
     if buf.numel() > nf + n * vox:
         buf[nf + n * vox:].zero_()

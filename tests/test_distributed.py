@@ -186,3 +186,21 @@ def test_all_gather_fields_rccl_two_ranks():
         out = mgr.dict()
         mp.spawn(_rccl_worker, args=(2, port, out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,shape", [(1, (16, 16, 16)), (2, (8, 12, 20)), (3, (5, 7, 9)), (1, (1, 1, 3))])
+def test_pack_kernel_writes_the_wire_format_of_the_host_path(hip_device, n, shape):
+    """pixie_pack_fields (one launch, device tensors) against the torch packing the gloo tests use (host tensors): same bytes,
+    incl. voxel counts that are not a multiple of 4 and the zero pad; and the round trip through unpack_fields."""
+    import torch
+    from pixie_amd import distributed as pd
+    g = torch.Generator().manual_seed(n + shape[2])
+    cont = torch.randn((n, 3) + shape, generator=g)
+    seg = torch.randint(0, 8, (n,) + shape, generator=g, dtype=torch.int32)
+    want = pd.pack_fields(cont, seg)
+    got = pd.pack_fields(cont.to(hip_device), seg.to(hip_device))
+    assert got.is_cuda and got.dtype == torch.uint8 and got.numel() == pd.wire_bytes(n, seg[0].numel()) == want.numel()
+    assert torch.equal(got.cpu(), want)
+    c2, s2 = pd.unpack_fields(got, 1, n, shape)
+    assert torch.equal(c2.cpu(), cont) and torch.equal(s2.cpu().to(torch.int32), seg)
