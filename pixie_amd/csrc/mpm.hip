@@ -49,9 +49,11 @@ constexpr int kWG = 256;                  // particles per work item / threads p
 // rows of the particle word array
 enum Row {
     R_X = 0, R_V = 3, R_F = 6, R_FT = 15, R_C = 24, R_VOL = 33, R_MASS, R_DENSITY, R_E, R_NU, R_MU, R_LAM, R_BULK, R_YS,
-    R_MATERIAL, R_SELECTION, R_PERM, R_XREF, R_COUNT = R_XREF + 3   // R_XREF: position at the last re-binning
+    R_MATERIAL, R_SELECTION, R_PERM, R_XLO, R_XREF = R_XLO + 3, R_COUNT = R_XREF + 3
+    // R_XLO: the low-order part of the position (set_scalar "compensated_x": x_true = x + xlo, |xlo| <= ulp(x)/2; zero otherwise);
+    // R_XREF: position at the last re-binning (must stay the last rows: bin_permute_kernel fills them from x)
 };
-static_assert(R_COUNT == 48, "row table");
+static_assert(R_COUNT == 51, "row table");
 
 struct MpmPtrs {
     int n, ng, nbk;   // particles, grid nodes per axis, blocks per axis
@@ -60,6 +62,7 @@ struct MpmPtrs {
     float *vol, *mass, *density, *E, *nu, *mu, *lam, *bulk, *ys;
     int *material, *selection, *perm;
     float* xref;                 // [3][n] positions at the last re-binning (drift measurement)
+    float* xlo;                  // [3][n] what the float32 position leaves behind (compensated_x), see particle_phase1
     float4 *gin, *gout;
     const int4* items;           // work list: (block id, first slot, count, 0)
     float4* part;                // [n_items][kTN]: (m*v.xyz, m) of each work item's tile, written by its P2G
@@ -81,6 +84,7 @@ struct StepParams {
     float damping;
     int do_damping;
     float rpic;
+    int comp_x;     // set_scalar "compensated_x": carry the rounding error of x += dt v in xlo (see particle_phase1)
     int trace;      // timing studies: bit 0 = workgroups stamp s_memrealtime around their phases into g_mpm_trace;
                     // bits 8.. = ablations for bottleneck hunting (RESULTS ARE WRONG with any of them set):
                     // 0x100 skip the LDS scatter atomics, 0x200 skip the workgroup scale reduction (fixed scale),
@@ -425,10 +429,21 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         const float sc = 4.0f * S.inv_dx;
 #pragma unroll
         for (int i = 0; i < 9; ++i) C.m[i] = B.m[i] * sc;
+        // x += dt v in float32 (mpm_utils.py:447) drops whatever of dt v lies below ulp(x)/2 = 6e-8 at x ~ 1: in a quiet scene
+        // (dt v ~ 1e-7) most of the motion, systematically -- the reference's own float32 behaviour, and the default here.
+        // "compensated_x" keeps what was dropped in xlo and feeds it into the next increment (Kahan): x is then the float32
+        // ROUNDING of the accumulated position instead of a sum of rounded increments (3 more words per particle each way).
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             v[d] = nv[d];
-            x[d] = x[d] + sp.dt * nv[d];
+            if (sp.comp_x) {
+                const float y = sp.dt * nv[d] + S.xlo[d * n + p];
+                const float t = x[d] + y;
+                S.xlo[d * n + p] = y - (t - x[d]);
+                x[d] = t;
+            } else {
+                x[d] = x[d] + sp.dt * nv[d];
+            }
             S.x[d * n + p] = x[d];
         }
         if (!DO_P2G) {  // the state a caller can observe: x, v, C, F_trial
@@ -1458,6 +1473,7 @@ struct pixie_mpm {
     int occupancy = 5;                       // register-allocation target of the fused kernel (waves per SIMD): 5 or 6
     int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
+    int comp_x = 0;                          // set_scalar "compensated_x"
     bool pmods_were_active = false;
     float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
     unsigned long long* tile_mask = nullptr; // [max_items][8] occupancy bits of the staged tiles
@@ -1514,7 +1530,7 @@ void bind_rows(pixie_mpm* h) {
     S.x = f + R_X * n; S.v = f + R_V * n; S.F = f + R_F * n; S.Ft = f + R_FT * n; S.C = f + R_C * n;
     S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
-    S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n;
+    S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n; S.xlo = f + R_XLO * n;
     S.items = h->items; S.part = h->part; S.tile_mask = h->tile_mask; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
 }
 
@@ -1613,6 +1629,7 @@ StepParams make_params(const pixie_mpm* h, double dt, double time) {
     sp.do_damping = (h->damping < 1.0f) ? 1 : 0;  // gate mpm_solver_warp.py:595
     sp.rpic = h->rpic;
     sp.trace = h->trace;
+    sp.comp_x = h->comp_x;
     sp.ms = h->ms;
     return sp;
 }
@@ -1956,6 +1973,7 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
         h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval;
         hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S.selection, n);
         h->mass_range_dirty = true;   // re-admitted particles count towards the mass contrast again
+        PX_CHECK_HIP(hipMemsetAsync(h->S.xlo, 0, (size_t)3 * n * sizeof(float), st));   // new positions carry no remainder
     }
     if (fi.is_int)
         hipLaunchKernelGGL(aos_to_soa_kernel<int>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int*)d_src, (int*)fi.ptr, n, fi.k, h->S.perm);
@@ -2055,6 +2073,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
 #ifdef PIXIE_DIAG
     else if (k == "trace") h->trace = (int)value;
 #endif
+    else if (k == "compensated_x") h->comp_x = value != 0.0 ? 1 : 0;
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)
