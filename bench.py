@@ -687,11 +687,17 @@ def cpu_baselines(args):
     for oc, ws in ((8, 0), (3, 1000)):
         cfg = UNetConfig(feature_channels=args.feature_channels, grid_size=Dc, out_channels=oc)
         nets.append((cfg, synthetic_state_dict(cfg, ws)))
+    # torch defaults to one thread per physical core of the HOST; a container with a CPU quota below that is oversubscribed 8x
+    default_threads = torch.get_num_threads()
+    if cpu_quota() and cpu_quota() < default_threads:
+        torch.set_num_threads(max(1, int(round(cpu_quota()))))
+    unet_threads = torch.get_num_threads()
     t0 = time.perf_counter()
     for cfg, sd in nets:
         unet_oracle.unet_forward(sd, cfg, feat)
     dt = time.perf_counter() - t0
-    out["unet"] = {"value": Dc ** 3 / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+    torch.set_num_threads(default_threads)
+    out["unet"] = {"value": Dc ** 3 / dt, "unit": "voxels/s", "cores": unet_threads, "kind": "port",
                    "sample": f"{Dc}^3x{args.feature_channels} grid (" + ("the headline size" if Dc == args.grid else f"NOT the {args.grid}^3 headline size: 1/{(args.grid // Dc) ** 3} of its voxels, same work per voxel")
                              + f"), SegmentationUNet+RegressionUNet forward once, oracle/unet_oracle.py on PyTorch CPU "
                              f"({dt:.1f} s; the reference's modules are not present on this box, the oracle is pinned to them)",
@@ -710,7 +716,7 @@ def cpu_baselines(args):
                 "sample": f"{n} particles, n_grid {n_grid}, {steps} substeps ({dt:.1f} s), {what}"}
 
     n = min(args.particles, 100_000)
-    # the OpenMP build of the C oracle: the thread count that is FASTEST on this host among {all, 1/4, 1/16} of the cores torch uses --
+    # the OpenMP build of the C oracle: the thread count that is FASTEST on this host among {the cgroup CPU quota; all, 1/4, 1/16 of torch's threads} --
     # probed in child processes (libgomp reads OMP_NUM_THREADS once), 10 substeps each; a container with a CPU quota below its
     # visible CPU count runs slower on more threads (the boxes of rounds 3-5: 1.4-1.8x one core on 128-256 threads)
     import subprocess
@@ -719,7 +725,10 @@ def cpu_baselines(args):
              "sc = mpm_ball_scene(%d, seed=0, n_grid=%d); o = OracleMPM(%d, sc['n_grid'], sc['grid_lim'], 'f32_omp'); o.load_initial_data(sc['x'], sc['vol'], sc['cov']);"
              "apply_scene(o, sc); o.run(sc['dt'], 1); t0 = time.perf_counter(); o.run(sc['dt'], 10); print(time.perf_counter() - t0)") % (REPO, n, args.n_grid, n)
     tried = {}
-    for th in sorted({max(1, torch.get_num_threads() // k) for k in (1, 4, 16)}, reverse=True):
+    cand = {max(1, torch.get_num_threads() // k) for k in (1, 4, 16)}
+    if cpu_quota():
+        cand.add(max(1, int(round(cpu_quota()))))     # what the container is actually scheduled on (r5c: 16 of 256 visible CPUs)
+    for th in sorted(cand, reverse=True):
         try:
             r = subprocess.run([sys.executable, "-c", probe], env={**os.environ, "OMP_NUM_THREADS": str(th)}, capture_output=True, text=True, timeout=120)
             tried[th] = float(r.stdout.strip().splitlines()[-1])

@@ -62,7 +62,12 @@ int pixie_mpm_fill_field(pixie_mpm* h, const char* name, double value, void* str
 
 /* Scalars of MPMModelStruct set by set_parameters_dict (mpm_solver_warp.py:386-433):
  * "rpic_damping","grid_v_damping_scale","hardening","xi","softening","plastic_viscosity",
- * "friction_angle","gx","gy","gz","time". */
+ * "friction_angle","gx","gy","gz","time".
+ * No reference counterpart: "compensated_x" (0, the default = the reference's float32 `x += dt v`, mpm_utils.py:447; 1 = the
+ * rounding error of that sum is carried in three more words per particle and fed into the next increment, so the stored x is the
+ * float32 rounding of the accumulated position: displacement error vs float64 4-8x smaller in quiet scenes, +5 % per substep),
+ * "scatter_bits" (0 = by the particle-mass contrast, 32, 64), "occupancy", "item_cap", "wide", "sparse_tiles", "grid_rb",
+ * "resort_interval" (kernel variants, see csrc/mpm.hip). */
 int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value);
 int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value);
 

@@ -101,19 +101,9 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned
 // The LDS tile holds the 16 channels of a chunk as fp32 planes [channel][voxel] (the same 64 bytes per voxel as the four
 // fp16 planes), a lane's B operand is one conflict-free ds_read_b32, its A operand one coalesced 4-byte load from the
 // [tap][c_in][c_out] weight array (L2-resident: 442 KB for the 64 -> 64 layer), fetched one tap ahead.
-// DPPB (round-5 experiment): the three taps of one (dz, dy) row read the SAME LDS row shifted by one voxel, and
-// lane l31 of a column block IS voxel x0 + l31 (TX = 32, stride 1), so the dx = 1, 2 fragments are the dx - 1 fragments moved down
-// one lane (v_mov_b32_dpp wave_shl:1, 4 per fragment) with only the block's last voxel -- lanes 31 and 63 -- reading LDS:
-// 8 full-wave + 16 two-lane ds_read_b128 per row instead of 24 full-wave ones.
-__device__ __forceinline__ f16x8 dpp_next_voxel(f16x8 v) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 w = __builtin_bit_cast(i32x4, v);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_update_dpp(w[q], w[q], 0x130, 0xf, 0xf, false);   // wave_shl:1: lane i <- lane i + 1
-    return __builtin_bit_cast(f16x8, w);
-}
-
-template <int KS, int MB, int NB, bool EX = false, bool DPPB = false>
+// (Round 5 tried taking the dx = 1, 2 B fragments of a row from the neighbouring lane with v_mov_b32_dpp wave_shl:1 instead of two more
+// LDS reads: 1.45 vs 1.30 ms on the dominant layer, 1.97 vs 1.78 J per launch -- profiles/r5c_conv_dppb_rejected.txt.)
+template <int KS, int MB, int NB, bool EX = false>
 __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
     extern __shared__ uint4 smem16[];
     constexpr int PAD = (KS == 3) ? 1 : 0;
@@ -340,7 +330,6 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
         for (int zy = 0; zy < KS * KS; ++zy) {
             const int dz = zy / KS, dy = zy - dz * KS;
             const int rowoff = (dz * A.HY + dy) * A.HX;
-            f16x8 bh[NB], bl[NB];
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
                 const int tap = zy * KS + dx;
@@ -355,22 +344,11 @@ __device__ __forceinline__ void conv3d_f16x3_body(const Conv16Args& A) {
                 // use and every tap then waits a full L2 round trip (measured: 31 us per chunk instead of 22; fetching two
                 // taps ahead instead of one gains nothing more)
                 __builtin_amdgcn_sched_barrier(0);
-                if (!DPPB || dx == 0) {
+                f16x8 bh[NB], bl[NB];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        bh[nb] = __builtin_bit_cast(f16x8, ldsHi[voff[nb] + rowoff + dx]);
-                        bl[nb] = __builtin_bit_cast(f16x8, ldsLo[voff[nb] + rowoff + dx]);
-                    }
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) { bh[nb] = dpp_next_voxel(bh[nb]); bl[nb] = dpp_next_voxel(bl[nb]); }
-                    if (l31 == 31) {     // the block's last voxel has no right-hand neighbour in the wave: its own (halo) voxel from LDS
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            bh[nb] = __builtin_bit_cast(f16x8, ldsHi[voff[nb] + rowoff + dx]);
-                            bl[nb] = __builtin_bit_cast(f16x8, ldsLo[voff[nb] + rowoff + dx]);
-                        }
-                    }
+                for (int nb = 0; nb < NB; ++nb) {
+                    bh[nb] = __builtin_bit_cast(f16x8, ldsHi[voff[nb] + rowoff + dx]);
+                    bl[nb] = __builtin_bit_cast(f16x8, ldsLo[voff[nb] + rowoff + dx]);
                 }
                 // small terms first, then the leading term; every accumulator is revisited after MB*NB MFMAs
 #pragma unroll
@@ -622,10 +600,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_exact_kernel(Conv16Args A) {
 __global__ __launch_bounds__(256, 2) void conv3d_f16x3_c64_fullres_kernel(Conv16Args A) {
     conv3d_f16x3_body<3, 2, 4>(A);
 }
-// the same with the dx = 1, 2 B fragments taken from the neighbouring lane (DPPB above): selected by PIXIE_CONV_DPPB=1
-__global__ __launch_bounds__(256, 2) void conv3d_f16x3_c64_fullres_dpp_kernel(Conv16Args A) {
-    conv3d_f16x3_body<3, 2, 4, false, true>(A);
-}
 
 // stats[tile][coutp][2] (fp32, from the conv epilogues) -> sums[c][2] (fp64), one workgroup per channel
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ stats, int n_tiles, int coutp, double* __restrict__ sums) {
@@ -826,8 +800,7 @@ int conv3d_f16x3_forward(const pixie_conv_desc* d, hipStream_t st) {
     }
     if (d->ksize == 3 && MB == 2 && NB == 4 && cin == 64 && d->c_out == 64 && d->stride == 1 && !d->upsample && d->c1 == 0 && !a.sk_w16 &&
         (long)a.OD * a.OH * a.OW >= 128L * 128 * 128) {
-        static const bool dppb = getenv("PIXIE_CONV_DPPB") != nullptr && getenv("PIXIE_CONV_DPPB")[0] == '1';
-        auto kern = (dppb && a.TX == 32) ? conv3d_f16x3_c64_fullres_dpp_kernel : conv3d_f16x3_c64_fullres_kernel;
+        auto kern = conv3d_f16x3_c64_fullres_kernel;
         PX_CHECK_HIP(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
         PX_CHECK_HIP(hipGetLastError());
