@@ -13,6 +13,7 @@ import sys
 src, out = sys.argv[1], sys.argv[2]
 tag = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(os.path.normpath(src))
 res = {}
+key_of = lambda scene: "100k_jelly" if scene == "jelly100k" else "1m_" + scene
 for path in sorted(glob.glob(os.path.join(src, "pmc_sq_*.txt"))):
     scene = os.path.basename(path)[len("pmc_sq_"):-4]
     best = None
@@ -25,7 +26,7 @@ for path in sorted(glob.glob(os.path.join(src, "pmc_sq_*.txt"))):
             best = (n, vals, line.split(" [")[0])
     if best:
         n, v, name = best
-        res.setdefault("1m_" + scene, {}).update({
+        res.setdefault(key_of(scene), {}).update({
             "valu_per_wave": round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1), "waves_per_launch": round(v["SQ_WAVES"]),
             "valu_active_frac": (round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_INSTS_VALU"], 3) if "SQ_ACTIVE_INST_VALU" in v else None),
             "pmc_dispatches": n, "kernel": name, "pmc_source": f"profiles/{tag}_pmc_sq_{scene}.txt"})
@@ -38,7 +39,7 @@ for path in sorted(glob.glob(os.path.join(src, "stats_*.csv"))):
         if "mpm_grid_block_kernel" in r["kernel"] and (grd is None or int(r["calls"]) > grd[0]):
             grd = (int(r["calls"]), float(r["avg_us"]))
     if blk:
-        res.setdefault("1m_" + scene, {}).update({"block_kernel_us": blk[1], "block_kernel_calls": blk[0], "grid_kernel_us": grd[1] if grd else None,
+        res.setdefault(key_of(scene), {}).update({"block_kernel_us": blk[1], "block_kernel_calls": blk[0], "grid_kernel_us": grd[1] if grd else None,
                                                   "stats_source": f"profiles/{tag}_stats_{scene}.csv"})
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

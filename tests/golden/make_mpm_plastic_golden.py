@@ -1,6 +1,7 @@
-"""Generates tests/golden/mpm_plastic_{sand,snow,metal}.npz: the C oracle (float64 and float32 builds) on the reference's own
+"""Generates tests/golden/mpm_plastic_{sand,snow,metal,mixed}.npz: the C oracle (float64 and float32 builds) on the reference's own
 plastic-material configurations -- third_party/PhysGaussian/config/objaverse/custom_{sand,snow,metal}_config.json: material
-parameters, n_grid, substep_dt, gravity, damping and boundary conditions as shipped -- with 100 000 particles for 200 substeps.
+parameters, n_grid, substep_dt, gravity, damping and boundary conditions as shipped -- with 100 000 particles for 200 substeps; `mixed` is the mixed-material scene bench.py times (pixie_amd.synthetic.PLASTIC_CONFIGS:
+material ids 0 / 1 / 2 / 5 drawn per particle, one set of solver scalars).
 
     python tests/golden/make_mpm_plastic_golden.py        (~3 min: six oracle runs in six threads)
 
@@ -28,7 +29,7 @@ from pixie_amd.synthetic import PLASTIC_CONFIGS, mpm_plastic_scene, start_plasti
 
 N, SEED, STRIDE = 100_000, 0, 16
 CHECKPOINTS = (50, 200)
-CONFIGS = {k: PLASTIC_CONFIGS[k] for k in ("sand", "snow", "metal")}
+CONFIGS = {k: PLASTIC_CONFIGS[k] for k in ("sand", "snow", "metal", "mixed")}   # `python make_mpm_plastic_golden.py mixed` regenerates one
 
 
 def plastic_scene(name):
@@ -61,10 +62,11 @@ def main():
         ever = float((ys_end != np.float64(np.float32(sc["params"].get("yield_stress", 0.0)))).mean())   # hardening / softening moved it
         results[(name, prec)] = (snaps, o.out_of_bounds, max(float(moved.mean()), ever))
 
-    threads = [threading.Thread(target=work, args=(n, p)) for n in CONFIGS for p in ("f64", "f32")]
+    names = [a for a in sys.argv[1:] if a in CONFIGS] or list(CONFIGS)
+    threads = [threading.Thread(target=work, args=(n, p)) for n in names for p in ("f64", "f32")]
     [t.start() for t in threads]; [t.join() for t in threads]
     rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-    for name in CONFIGS:
+    for name in names:
         s64, oob64, yielding = results[(name, "f64")]; s32 = results[(name, "f32")][0]
         res = dict(n=N, seed=SEED, stride=STRIDE, checkpoints=np.array(CHECKPOINTS), oob=oob64, yielded_fraction=yielding)
         x0 = plastic_scene(name)["x"].astype(np.float64)

@@ -647,13 +647,14 @@ def test_compensated_positions_follow_the_float64_trajectory(hip_device):
     assert np.array_equal(get(comp, "x"), get(plain, "x"))
 
 
-@pytest.mark.parametrize("material", ["sand", "snow", "metal"])
+@pytest.mark.parametrize("material", ["sand", "snow", "metal", "mixed"])
 @pytest.mark.parametrize("bits", SCATTER_MODES)
 def test_plastic_reference_configs_100k(hip_device, material, bits):
     """The reference's own plastic configurations (PG/config/objaverse/custom_{sand,snow,metal}_config.json: parameters,
     n_grid 200 / 120, substep 2e-5 / 1e-5, gravity, damping, boundary conditions) with 100 000 particles for 200 substeps,
     against the float64 C oracle's committed trajectory (tests/golden/make_mpm_plastic_golden.py, which perturbs the initial
-    F and v so that the return mappings work from the first substep).  Bar: x and F <= 1e-4 outright; v (on the scale of
+    F and v so that the return mappings work from the first substep).  "mixed": the mixed-material scene bench.py times -- ids
+    0 / 1 / 2 / 5 drawn per particle under one set of solver scalars, so every wave holds all four constitutive branches.  Bar: x and F <= 1e-4 outright; v (on the scale of
     rms|v|) and the yield stress <= max(1e-4, DRIFT_K x the float32 oracle's own drift)."""
     import os
     import sys
