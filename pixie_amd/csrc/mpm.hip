@@ -900,21 +900,41 @@ __device__ __forceinline__ int cell_in_block(const MpmPtrs& S, int p) {
     }
     return c;
 }
+// Material class of a particle for the ordering inside a block: the constitutive branches of return_map_and_stress.  A block
+// that mixes materials (material_mode=neural uploads an id per particle, PG/material_field.py:343-363) is laid out class by
+// class, round-robin by cell inside a class, so that a wave runs ONE branch instead of all of them (mixed 1 M scene: 1955 ->
+// VALU instructions per wave, see profiles/r5*); a single-material block -- every block of a single-material scene -- keeps the
+// order it always had.
+constexpr int kMatClasses = 7;
+__device__ __forceinline__ int material_class(int material) {
+    return material == 0 ? 0 : material == 1 ? 1 : material == 2 ? 2 : material == 3 ? 3 : material == 5 ? 4 : material == 6 ? 5 : 6;
+}
 __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const int* __restrict__ counts, const int* __restrict__ offsets,
                                                               const int* __restrict__ order, int* __restrict__ cellk,
                                                               int* __restrict__ rank, int* __restrict__ order2) {
-    __shared__ int cc[kBS * kBS * kBS];
+    constexpr int kCells = kBS * kBS * kBS;
+    __shared__ int cc[kMatClasses * kCells];     // particles per (class, cell)
+    __shared__ int s_class_base[kMatClasses];
     __shared__ int2 s_tile[256];
     const int b = blockIdx.x;
     const int cnt = counts[b];
     if (cnt == 0) return;
     const int off = offsets[b];
-    if (threadIdx.x < kBS * kBS * kBS) cc[threadIdx.x] = 0;
+    for (int t = threadIdx.x; t < kMatClasses * kCells; t += 256) cc[t] = 0;
     __syncthreads();
     for (int t = threadIdx.x; t < cnt; t += 256) {
-        const int c = cell_in_block(S, order[off + t]);
+        const int p = order[off + t];
+        const int c = material_class(S.material[p]) * kCells + cell_in_block(S, p);   // key: (class, cell)
         cellk[off + t] = c;
         atomicAdd(&cc[c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int m = 0; m < kMatClasses; ++m) {
+            s_class_base[m] = acc;
+            for (int k = 0; k < kCells; ++k) acc += cc[m * kCells + k];
+        }
     }
     __syncthreads();
     for (int t0 = 0; t0 < cnt; t0 += 256) {
@@ -933,11 +953,12 @@ __global__ __launch_bounds__(256) void bin_local_order_kernel(MpmPtrs S, const i
                 r += (e.x == c && e.y < p) ? 1 : 0;
             }
         }
-        if (mine) {
-            int pos = 0;
-            for (int k = 0; k < kBS * kBS * kBS; ++k) {
-                const int n = cc[k];
-                pos += min(n, r) + ((k < c && n > r) ? 1 : 0);
+        if (mine) {      // slot = particles of earlier classes + (round r, cell) position inside the class
+            const int m = c / kCells, cl = c - m * kCells;
+            int pos = s_class_base[m];
+            for (int k = 0; k < kCells; ++k) {
+                const int n = cc[m * kCells + k];
+                pos += min(n, r) + ((k < cl && n > r) ? 1 : 0);
             }
             order2[off + pos] = p;
         }
@@ -1969,6 +1990,7 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     PX_REQUIRE(find_field(h, nm, &fi), "set_field: unknown field '%s'", name);
     PX_REQUIRE(count == (int64_t)n * fi.k, "set_field(%s): expected %lld scalars, got %lld", name, (long long)n * fi.k, (long long)count);
     if (nm == "mass" || nm == "selection") { h->mass_range_dirty = true; h->needs_sort = true; }
+    if (nm == "material") h->needs_sort = true;     // the order inside a block goes by material class
     if (nm == "x") {   // positions replaced: binning stale, frozen particles get another chance
         h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval;
         hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S.selection, n);
@@ -2040,6 +2062,7 @@ int pixie_mpm_fill_field(pixie_mpm* h, const char* name, double value, void* str
     else
         hipLaunchKernelGGL(fill_kernel<float>, dim3(cdiv(cnt, 256)), dim3(256), 0, as_stream(stream), (float*)fi.ptr, cnt, (float)value);
     PX_CHECK_HIP(hipGetLastError());
+    if (std::string(name) == "material") h->needs_sort = true;
     return 0;
 }
 
@@ -2135,6 +2158,7 @@ int pixie_mpm_apply_additional_params(pixie_mpm* h, const double point[3], const
     hipLaunchKernelGGL(additional_params_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, pt, sz,
                        (float)E, (float)nu, (float)density, material);
     PX_CHECK_HIP(hipGetLastError());
+    h->needs_sort = true;      // materials changed: the order inside a block goes by material class
     return 0;
 }
 
@@ -2145,6 +2169,7 @@ int pixie_mpm_apply_additional_params_batch(pixie_mpm* h, int64_t n_boxes, const
     hipLaunchKernelGGL(additional_params_batch_kernel, dim3(cdiv(h->S.n, 256)), dim3(256), 0, as_stream(stream), h->S, (long)n_boxes, d_boxes,
                        d_params, reinterpret_cast<const int*>(d_material));
     PX_CHECK_HIP(hipGetLastError());
+    h->needs_sort = true;      // materials changed: the order inside a block goes by material class
     return 0;
 }
 

@@ -116,6 +116,26 @@ def test_round_robin_slot_is_a_permutation_ordered_by_rank_then_cell():
         assert len(set(first_round)) == len(first_round)
 
 
+def test_material_classes_come_first_and_a_single_class_keeps_the_old_order():
+    """Round 5: slot = (particles of earlier material classes) + the round-robin position inside the class, counts per
+    (class, cell) -- mpm.hip: bin_local_order_kernel.  A permutation ordered by (class, rank, cell); with one class present it is
+    the formula above unchanged, so single-material scenes keep their layout (and their bits)."""
+    rng = np.random.default_rng(7)
+    for trial in range(30):
+        classes = 1 if trial < 5 else int(rng.integers(2, 8))
+        n = rng.integers(0, 6, (7, 64))
+        n[classes:] = 0
+        base = np.concatenate([[0], np.cumsum(n.sum(1))])[:7]
+        entries = [(m, c, r) for m in range(7) for c in range(64) for r in range(int(n[m, c]))]
+        pos = {(m, c, r): int(base[m] + np.minimum(n[m], r).sum() + np.count_nonzero((np.arange(64) < c) & (n[m] > r))) for m, c, r in entries}
+        assert sorted(pos.values()) == list(range(len(entries)))
+        by_pos = sorted(entries, key=lambda e: pos[e])
+        assert by_pos == sorted(entries, key=lambda e: (e[0], e[2], e[1]))       # class-major, then rank, then cell
+        if classes == 1:
+            old = {(c, r): int(np.minimum(n[0], r).sum() + np.count_nonzero((np.arange(64) < c) & (n[0] > r))) for _, c, r in entries}
+            assert all(pos[(0, c, r)] == old[(c, r)] for _, c, r in entries)
+
+
 # ---- exact mode: 64-bit fixed point through the double adder (mpm.hip: to_fixed / from_fixed / scale_for) ----
 K_MAGIC = 6755399441055744.0            # 1.5 * 2^52
 
