@@ -565,19 +565,10 @@ def bench_mpm_multi_scene(args, device, particles, n_grid, substeps, n_scenes):
     import threading
     scenes = [mpm_ball_scene(particles, seed=10 + i, n_grid=n_grid) for i in range(n_scenes)]
     solvers = [_mpm_solver(sc) for sc in scenes]    # (forcing the five-waves-per-SIMD block kernel changes nothing here: profiles/r4k_mpm_multi_scene_variant.txt)
-    streams = [torch.cuda.Stream(device) for _ in range(n_scenes)]
+    from pixie_amd.mpm_solver import run_batch
 
-    def work(i, n):
-        torch.cuda.set_device(device)
-        with torch.cuda.stream(streams[i]):
-            solvers[i].run(scenes[i]["dt"], n)
-
-    def run_all(n):
-        th = [threading.Thread(target=work, args=(i, n)) for i in range(n_scenes)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    def run_all(n):     # the product's batch entry: one HIP stream and one host thread per scene (pixie_amd/mpm_solver.py: run_batch)
+        run_batch(solvers, scenes[0]["dt"], n)
         torch.cuda.synchronize()
 
     run_all(50)

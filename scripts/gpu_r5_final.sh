@@ -54,6 +54,20 @@ run_pmc mpm_1m_fetch FETCH_SIZE -- $M1M
 run_pmc mpm_1m_write WRITE_SIZE -- $M1M
 python scripts/pmc_traffic.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 timeout 120 scripts/microbench/mfma_lds.exe > $OUT/mfma_lds_microbench.txt 2>&1
+# single-material scenes keep their bits under the class-major ordering inside blocks: state hashes against the library of the commit
+# before it (scripts/_ab/libpixie_hip_prev.so = `python scripts/build_variant.py 8a97578 ...`)
+if [ -f scripts/_ab/libpixie_hip_prev.so ]; then
+  cp pixie_amd/libpixie_hip.so /tmp/new.so
+  for which in new prev; do
+    if [ $which = new ]; then cp /tmp/new.so pixie_amd/libpixie_hip.so; else cp scripts/_ab/libpixie_hip_prev.so pixie_amd/libpixie_hip.so; fi
+    echo "== $which" >> $OUT/state_hash.txt
+    timeout 200 python scripts/mpm_state_hash.py 100000 50 400 2>/dev/null | grep sha256 >> $OUT/state_hash.txt
+    timeout 200 python scripts/mpm_state_hash.py 1000000 120 200 2>/dev/null | grep sha256 >> $OUT/state_hash.txt
+    timeout 200 python scripts/mpm_state_hash.py 100000 50 400 64 2>/dev/null | grep sha256 >> $OUT/state_hash.txt
+  done
+  cp /tmp/new.so pixie_amd/libpixie_hip.so
+  cat $OUT/state_hash.txt
+fi
 tail -4 $OUT/cold_build.log; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu_tail.txt | head; tail -2 $OUT/smoke.log; tail -4 $OUT/reference_drivers_stdout.log | cut -c1-300
 tail -2 $OUT/bench.err; wc -c $OUT/bench.json; cat $OUT/bench.json; echo
 head -6 $OUT/kernel_stats.csv | cut -c1-160; cat $OUT/mpm_counters.json | grep -E "\"1m_|valu_per_wave|block_kernel_us|grid_kernel_us"; grep -A8 '"mpm_1m' $OUT/pmc_traffic.json | head -24

@@ -338,6 +338,28 @@ def test_deferred_substeps_keep_the_stream_they_were_queued_on(hip_device):
     assert np.array_equal(get(a, "x"), get(b, "x")) and np.array_equal(get(a, "F_trial"), get(b, "F_trial"))
 
 
+def test_run_batch_equals_running_the_scenes_one_after_the_other(hip_device):
+    """pixie_amd.mpm_solver.run_batch: several independent scenes on their own HIP streams and host threads (the batch
+    configuration of BASELINE configs[3]) -- every scene must end in exactly the state it reaches alone, and the caller's stream
+    must be ordered after all of them (the export below runs on the current stream with no synchronisation in between)."""
+    from pixie_amd.mpm_solver import run_batch
+    scs = [mpm_ball_scene(30_000, seed=40 + i, n_grid=40, scenario=("tree", "ball", "tree")[i]) for i in range(3)]
+    batch, alone = [make_hip(sc) for sc in scs], [make_hip(sc) for sc in scs]
+    for k in range(3):                       # three calls: the streams are kept and re-used, queued substeps are flushed first
+        batch[1].p2g2p(0, scs[1]["dt"])      # a deferred substep on one of them
+        alone[1].p2g2p(0, scs[1]["dt"])
+        run_batch(batch, scs[0]["dt"], 40)
+        xs = [b.export_particle_x_to_torch().clone() for b in batch]
+        for a in alone:
+            a.run(scs[0]["dt"], 40)
+        for b, a, x in zip(batch, alone, xs):
+            assert torch.equal(x, a.export_particle_x_to_torch())
+            for f in ("v", "C", "F_trial"):
+                assert np.array_equal(get(b, f), get(a, f)), f
+            assert abs(b.time - a.time) < 1e-12
+    run_batch([], 1e-4, 5)
+
+
 def test_deferred_substeps_order_the_observing_stream_after_them(hip_device):
     """the caller synchronises as it would for the reference's eager kernels -- wait_stream(side) right after the
     p2g2p() loop, BEFORE anything flushes the queue -- so that wait sees an empty stream.  The flush (here: the next batch on the
