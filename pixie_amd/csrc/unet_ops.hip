@@ -461,6 +461,7 @@ extern "C" int pixie_pack_fields(const float* d_cont, const int32_t* d_seg_pred,
                                  void* stream) {
     const int64_t n_float = 3 * n_scenes * spatial, n_vox = n_scenes * spatial;
     PX_REQUIRE(d_cont && d_seg_pred && d_wire && n_scenes > 0 && spatial > 0, "pixie_pack_fields: bad arguments");
+    PX_REQUIRE((((uintptr_t)d_cont | (uintptr_t)d_seg_pred | (uintptr_t)d_wire) & 15) == 0, "pixie_pack_fields: pointers must be 16-byte aligned");
     PX_REQUIRE(wire_bytes >= 4 * n_float + n_vox && wire_bytes < 4 * n_float + n_vox + 16, "pixie_pack_fields: wire buffer of %lld bytes for %lld scenes x %lld voxels",
                (long long)wire_bytes, (long long)n_scenes, (long long)spatial);
     const int64_t threads = (std::max(n_float, n_vox) + 3) / 4;

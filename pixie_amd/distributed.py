@@ -65,6 +65,10 @@ def pack_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor) -> torch.Tensor
         from . import _lib
         cont = cont_pred.detach().to(torch.float32).contiguous()
         seg = seg_pred.to(torch.int32).contiguous()
+        if cont.data_ptr() % 16:       # the kernel moves 16-byte words: a contiguous VIEW at an odd offset is copied first
+            cont = cont.clone()
+        if seg.data_ptr() % 16:
+            seg = seg.clone()
         _lib.check(_lib.load().pixie_pack_fields(C.c_void_p(cont.data_ptr()), C.c_void_p(seg.data_ptr()), n, vox, C.c_void_p(buf.data_ptr()),
                                                  buf.numel(), _lib.current_stream_ptr()), "pixie_pack_fields")
         return buf

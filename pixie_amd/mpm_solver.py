@@ -670,6 +670,8 @@ def run_batch(solvers, dt, n_substeps, streams=None):
     if not solvers:
         return
     dev = solvers[0].device
+    if any(s.device != dev for s in solvers):
+        raise ValueError("run_batch: the solvers must live on one device (scenes are sharded across GPUs by process, pixie_amd/distributed.py)")
     cur = torch.cuda.current_stream(dev)
     if streams is None:
         streams = []

@@ -204,3 +204,6 @@ def test_pack_kernel_writes_the_wire_format_of_the_host_path(hip_device, n, shap
     assert torch.equal(got.cpu(), want)
     c2, s2 = pd.unpack_fields(got, 1, n, shape)
     assert torch.equal(c2.cpu(), cont) and torch.equal(s2.cpu().to(torch.int32), seg)
+    if n > 1:     # a contiguous view at an offset that is not a multiple of 16 bytes (odd voxel count): copied before the 16-byte moves
+        dc, ds = cont.to(hip_device), seg.to(hip_device)
+        assert torch.equal(pd.pack_fields(dc[1:], ds[1:]).cpu(), pd.pack_fields(cont[1:], seg[1:]))
