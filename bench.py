@@ -707,40 +707,48 @@ def cpu_baselines(args):
                 "sample": f"{n} particles, n_grid {n_grid}, {steps} substeps ({dt:.1f} s), {what}"}
 
     n = min(args.particles, 100_000)
-    # the OpenMP build of the C oracle: the thread count that is FASTEST on this host among {the cgroup CPU quota; all, 1/4, 1/16 of torch's threads} --
-    # probed in child processes (libgomp reads OMP_NUM_THREADS once), 10 substeps each; a container with a CPU quota below its
-    # visible CPU count runs slower on more threads (the boxes of rounds 3-5: 1.4-1.8x one core on 128-256 threads)
+    # The OpenMP build of the C oracle (pinned to the reference's kernels, tests/test_mpm_ref_golden.py; OpenMP over particles / grid
+    # nodes, atomic-free P2G: particles sorted into 4^3-cell tiles, 8 colours of tiles one after the other) runs in CHILD processes:
+    # libgomp reads OMP_NUM_THREADS once, when it is first loaded, and this process has long since loaded it.  The thread count is the
+    # one that is FASTEST on this host among {the cgroup CPU quota; all, 1/4, 1/16 of torch's threads}, probed with 10 substeps each --
+    # a container with a CPU quota below its visible CPU count runs slower on more threads (the boxes of rounds 3-5 show 256 logical
+    # CPUs and schedule 16: 1.4-1.8x one core on 128-256 threads, 5-6x on 16).
     import subprocess
-    best = None
-    probe = ("import sys, time; sys.path.insert(0, %r); from oracle.mpm_oracle import OracleMPM; from pixie_amd.synthetic import apply_scene, mpm_ball_scene;"
-             "sc = mpm_ball_scene(%d, seed=0, n_grid=%d); o = OracleMPM(%d, sc['n_grid'], sc['grid_lim'], 'f32_omp'); o.load_initial_data(sc['x'], sc['vol'], sc['cov']);"
-             "apply_scene(o, sc); o.run(sc['dt'], 1); t0 = time.perf_counter(); o.run(sc['dt'], 10); print(time.perf_counter() - t0)") % (REPO, n, args.n_grid, n)
-    tried = {}
+    child = ("import sys, time; sys.path.insert(0, %r); from oracle.mpm_oracle import OracleMPM; from pixie_amd.synthetic import apply_scene, mpm_ball_scene;"
+             "n, ng, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]);"
+             "sc = mpm_ball_scene(n, seed=0, n_grid=ng); o = OracleMPM(n, sc['n_grid'], sc['grid_lim'], 'f32_omp'); o.load_initial_data(sc['x'], sc['vol'], sc['cov']);"
+             "apply_scene(o, sc); o.run(sc['dt'], 1); t0 = time.perf_counter(); o.run(sc['dt'], steps); print(time.perf_counter() - t0)") % REPO
+
+    def omp_seconds(threads, n_, ng_, steps_):
+        r = subprocess.run([sys.executable, "-c", child, str(n_), str(ng_), str(steps_)], env={**os.environ, "OMP_NUM_THREADS": str(threads)},
+                           capture_output=True, text=True, timeout=600)
+        return float(r.stdout.strip().splitlines()[-1])
+
+    tried, best = {}, None
     cand = {max(1, torch.get_num_threads() // k) for k in (1, 4, 16)}
     if cpu_quota():
         cand.add(max(1, int(round(cpu_quota()))))     # what the container is actually scheduled on (r5c: 16 of 256 visible CPUs)
     for th in sorted(cand, reverse=True):
         try:
-            r = subprocess.run([sys.executable, "-c", probe], env={**os.environ, "OMP_NUM_THREADS": str(th)}, capture_output=True, text=True, timeout=120)
-            tried[th] = float(r.stdout.strip().splitlines()[-1])
+            tried[th] = omp_seconds(th, n, args.n_grid, 10)
             if best is None or tried[th] < tried[best]:
                 best = th
         except Exception:
             pass
     cores = best or torch.get_num_threads()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    # the stated multi-core baseline: the C oracle (pinned to the reference's kernels, tests/test_mpm_ref_golden.py) with
-    # OpenMP over particles / grid nodes and an atomic-free P2G (particles sorted into 4^3-cell tiles, 8 colours of tiles one
-    # after the other: oracle/mpm_oracle.c), on the host's cores; the scalar build on one core beside it
-    out["mpm"] = timed(lambda n_, sc: OracleMPM(n_, sc["n_grid"], sc["grid_lim"], "f32_omp"), n, args.n_grid, 200,
-                       f"oracle/mpm_oracle.c float32, OpenMP on {cores} host threads (atomic-free coloured P2G)", cores)
+
+    def timed_omp(n_, ng_, steps_):
+        dt = omp_seconds(cores, n_, ng_, steps_)
+        return {"value": n_ * steps_ / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+                "sample": f"{n_} particles, n_grid {ng_}, {steps_} substeps ({dt:.1f} s), oracle/mpm_oracle.c float32, OpenMP on {cores} host threads "
+                          "(atomic-free coloured P2G; child process)"}
+    out["mpm"] = timed_omp(n, args.n_grid, 400)
     out["mpm"]["thread_probe_s_per_10_substeps"] = {str(k): round(v, 3) for k, v in tried.items()}
     out["mpm"]["cpu_quota"] = cpu_quota()
     out["mpm"]["single_core"] = timed(lambda n_, sc: OracleMPM(n_, sc["n_grid"], sc["grid_lim"], "f32"), n, args.n_grid, 20,
                                       "oracle/mpm_oracle.c float32, scalar C", 1)
     if not (args.no_mpm or args.no_mpm_large):
-        out["mpm_1m"] = timed(lambda n_, sc: OracleMPM(n_, sc["n_grid"], sc["grid_lim"], "f32_omp"), 1_000_000, 120, 30,
-                              f"oracle/mpm_oracle.c float32, OpenMP on {cores} host threads", cores)
+        out["mpm_1m"] = timed_omp(1_000_000, 120, 60)
     return out
 
 
