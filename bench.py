@@ -317,6 +317,20 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
         parts["cont_forward_ms"] += evs[1].elapsed_time(evs[2]) / 3
         parts["combine_and_stack_ms"] += evs[2].elapsed_time(evs[3]) / 3
     parts = {k: round(v, 3) for k, v in parts.items()}
+    # the one kernel of the field exchange (13 B/voxel wire buffer), timed on the device whatever the world size: with N ranks the
+    # all-gather follows it; with one rank nothing is packed in the step itself
+    try:
+        _, sp_, _, cp_ = predict_material_field(seg, cont, feat)
+        pd.pack_fields(cp_, sp_)
+        evs[0].record()
+        for _ in range(10):
+            pd.pack_fields(cp_, sp_)
+        evs[1].record()
+        torch.cuda.synchronize()
+        parts["pack_fields_us"] = round(1e3 * evs[0].elapsed_time(evs[1]) / 10, 2)
+    except Exception as exc:      # (never loses the run)
+        parts["pack_fields_us"] = None
+        print(f"bench.py: pack_fields timing failed: {exc}", file=sys.stderr)
     parts["telemetry_before"] = tele0
     parts["telemetry_during"] = tele_mid
     flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
@@ -933,6 +947,8 @@ def compact_line(d, detail_path=None):
     line["roofline"] = None if rf is None else {**_pick(rf, "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
                                                       "mfma_hw_frac", "mfma_hw_frac_of_sustained"),
                                                 "kernel": rf["kernel"].split(" (")[0]}
+    if (d.get("step_decomposition") or {}).get("pack_fields_us") is not None:
+        line["pack_fields_us"] = d["step_decomposition"]["pack_fields_us"]
     tele = (d.get("step_decomposition") or {}).get("telemetry_during") or {}
     if tele:
         line["telemetry"] = _pick(tele, "sclk_mhz", "power_w", "temp_c")
