@@ -331,6 +331,23 @@ def bench_unet(args, rank, world, device, precision_override=None, steps=None, w
     except Exception as exc:      # (never loses the run)
         parts["pack_fields_us"] = None
         print(f"bench.py: pack_fields timing failed: {exc}", file=sys.stderr)
+    # what a caller that hands over HOST buffers pays on top (the reference's DataLoader does: inference_combined.py:247-256 with
+    # pin_memory=True, then `.to(rank)`): one upload of the fp32 feature grid.  Never part of `value` (inputs are resident when the
+    # timed region starts); reported so that the PCIe-inclusive rate can be derived.
+    try:
+        host = torch.empty(feat.shape, dtype=feat.dtype, pin_memory=True)
+        dst = torch.empty_like(feat)
+        dst.copy_(host, non_blocking=True)
+        evs[0].record()
+        for _ in range(3):
+            dst.copy_(host, non_blocking=True)
+        evs[1].record()
+        torch.cuda.synchronize()
+        parts["h2d_feature_grid_ms_pinned"] = round(evs[0].elapsed_time(evs[1]) / 3, 2)
+        del host, dst
+    except Exception as exc:
+        parts["h2d_feature_grid_ms_pinned"] = None
+        print(f"bench.py: H2D timing failed: {exc}", file=sys.stderr)
     parts["telemetry_before"] = tele0
     parts["telemetry_during"] = tele_mid
     flops_scene = conv_flops(seg.cfg) + conv_flops(cont.cfg)
@@ -634,8 +651,23 @@ def bench_pipeline(args, device, substeps=1000):
         walls.append(1e3 * (time.perf_counter() - t0))
         for k_, v_ in tm.items():
             parts[k_] = parts.get(k_, 0.0) + v_ / 2
+    # the same scenes as a software-pipelined batch: the rollout of scene i on a side stream under the networks of scene i + 1
+    from pixie_amd.pipeline import neural_scene_batch
+    nb = 4
+    batch_kw = dict(n_grid=sc["n_grid"], grid_lim=sc["grid_lim"], dt=sc["dt"], n_substeps=substeps, params=sc["params"], min_bounds=sc["min_bounds"],
+                    max_bounds=sc["max_bounds"], to_field_frame=lambda x: (x - 1.0) * sc["field_scale"], configure=lambda s: s.add_bounding_box(),
+                    ranges=sc["ranges"])
+    neural_scene_batch(seg, cont, [(feat, mask, x0, vol)] * 2, **batch_kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = neural_scene_batch(seg, cont, [(feat, mask, x0, vol)] * nb, **batch_kw)
+    torch.cuda.synchronize()
+    batch_ms = 1e3 * (time.perf_counter() - t0) / nb
+    batch_finite = all(bool(torch.isfinite(s_.get_field("x")).all()) for s_ in done)
+    del done
     mats = torch.bincount(solver.get_field("material").to(torch.int64), minlength=8).tolist()
     return {"pipeline_ms_per_scene": sum(walls) / 2, "parts_ms": {k_: round(v_, 3) for k_, v_ in parts.items()}, "substeps": substeps,
+            "pipelined_batch_ms_per_scene": batch_ms, "pipelined_batch_scenes": nb, "pipelined_batch_finite": batch_finite,
             "finite": bool(torch.isfinite(solver.get_field("x")).all()), "out_of_bounds": solver.out_of_bounds, "particles_per_material_id": mats,
             "workload": f"{D}^3 x {C} feature grid -> SegmentationUNet + RegressionUNet -> field transfer onto {args.particles} particles -> "
                         f"{substeps} substeps (n_grid {args.n_grid}, dt {sc['dt']:g}); device-resident, 1 scene"}
@@ -947,6 +979,8 @@ def compact_line(d, detail_path=None):
     line["roofline"] = None if rf is None else {**_pick(rf, "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
                                                       "mfma_hw_frac", "mfma_hw_frac_of_sustained"),
                                                 "kernel": rf["kernel"].split(" (")[0]}
+    if (d.get("step_decomposition") or {}).get("h2d_feature_grid_ms_pinned") is not None:
+        line["h2d_feature_grid_ms_pinned"] = d["step_decomposition"]["h2d_feature_grid_ms_pinned"]     # not in `value`: inputs are resident
     if (d.get("step_decomposition") or {}).get("pack_fields_us") is not None:
         line["pack_fields_us"] = d["step_decomposition"]["pack_fields_us"]
     tele = (d.get("step_decomposition") or {}).get("telemetry_during") or {}
@@ -1024,6 +1058,7 @@ def compact_line(d, detail_path=None):
     if d.get("pipeline_configs2"):
         pp = d["pipeline_configs2"]
         line["pipeline_ms_per_scene"] = _r(pp["pipeline_ms_per_scene"])
+        line["pipeline_batch_ms_per_scene"] = _r(pp.get("pipelined_batch_ms_per_scene"))     # rollout of scene i under the networks of scene i + 1
         line["pipeline_parts_ms"] = {k.replace("_ms", ""): _r(v) for k, v in pp["parts_ms"].items() if k != "total_ms"}
     if d.get("field_to_particles"):
         line["field_to_particles_ms"] = _r(d["field_to_particles"]["ms"])

@@ -63,3 +63,61 @@ def neural_scene_rollout(seg_network, cont_network, feat_grid: torch.Tensor, mas
         for name, a, b in (("unet_ms", 0, 1), ("solver_setup_ms", 1, 2), ("field_to_particles_ms", 2, 3), ("rollout_ms", 3, 4), ("total_ms", 0, 4)):
             timings[name] = ev[a].elapsed_time(ev[b])
     return solver, pred, conf
+
+
+def neural_scene_batch(seg_network, cont_network, scenes, *, n_grid: int, grid_lim: float, dt: float, n_substeps: int,
+                       params: Dict, min_bounds: Sequence[float], max_bounds: Sequence[float],
+                       to_field_frame: Callable[[torch.Tensor], torch.Tensor], configure: Optional[Callable] = None,
+                       k: int = 10, nn_distance_threshold: float = 0.1, ranges: Optional[Dict[str, float]] = None):
+    """A batch of scenes through `neural_scene_rollout`'s stages, software-pipelined across two kinds of work that do not compete:
+    the rollout of scene i (a 100 k-particle step loop: two latency-bound launches per substep that fill 40 % of the chip) runs on a
+    side stream, issued from a host thread of its own, WHILE the networks of scene i + 1 (matrix-core bound) run on the caller's
+    stream.  `scenes`: an iterable of (feat_grid, mask, particle_x, particle_vol) device tensors.  Returns the solvers, in order;
+    each ends in exactly the state `neural_scene_rollout` leaves it in (tests/test_pipeline_hip.py).  The caller's stream is ordered
+    after every rollout when this returns.  (BASELINE configs[3]: a batch of scenes per GPU; measured in bench.py: pipeline leg.)"""
+    import threading
+    solvers, threads, errors = [], [], []
+    side = None
+    cur = None
+
+    def roll(solver, stream):
+        try:
+            torch.cuda.set_device(solver.device)
+            with torch.cuda.stream(stream):
+                solver.run(dt, n_substeps)
+        except Exception as exc:
+            errors.append(exc)
+
+    for i, (feat_grid, mask, particle_x, particle_vol) in enumerate(scenes):
+        dev = feat_grid.device
+        if dev.type != "cuda":
+            raise RuntimeError("neural_scene_batch runs on a HIP device only (no CPU fallback)")
+        if side is None:
+            cur = torch.cuda.current_stream(dev)
+            side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        with torch.no_grad():
+            combined, _, _, _ = predict_material_field(seg_network, cont_network, feat_grid)
+        solver = MPM_Simulator_WARP(10)
+        solver.load_initial_data_from_torch(particle_x, particle_vol, None, n_grid=n_grid, grid_lim=grid_lim)
+        solver.set_parameters_dict(params)
+        if configure is not None:
+            configure(solver)
+        apply_material_field_to_solver(solver, combined[0], mask, min_bounds, max_bounds, to_field_frame(particle_x.to(dev)),
+                                       k_smoothing_neighbors=k, nn_distance_threshold=nn_distance_threshold, ranges=ranges)
+        solver.flush()
+        st = side[i % 2]
+        if len(threads) >= 2:
+            threads[-2].join()          # the previous user of this side stream has issued all its launches
+        st.wait_stream(cur)             # set-up and field transfer of this scene are in front of its rollout
+        t = threading.Thread(target=roll, args=(solver, st))
+        t.start()
+        threads.append(t)
+        solvers.append(solver)
+    for t in threads:
+        t.join()
+    if side is not None:
+        for st in side:
+            cur.wait_stream(st)
+    if errors:
+        raise errors[0]
+    return solvers

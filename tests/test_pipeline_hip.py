@@ -77,3 +77,25 @@ def test_device_resident_route_equals_the_staged_route(hip_device, tmp_path, D, 
     x = sa.get_field("x")
     assert bool(torch.isfinite(x).all()) and sa.out_of_bounds == 0
     assert float((x.cpu() - x0).norm()) > 0                    # it moved
+
+
+def test_pipelined_batch_equals_scene_by_scene(hip_device):
+    """neural_scene_batch overlaps the rollout of scene i (side stream, own host thread) with the networks of scene i + 1: every
+    scene must end in the state the plain scene-by-scene route gives it, bit for bit."""
+    from pixie_amd.pipeline import neural_scene_batch, neural_scene_rollout
+    D, n, substeps = 32, 15_000, 80
+    seg, cont = _networks(hip_device, D, 64)
+    scs = [pipeline_scene(D, 64, n, seed=s, n_grid=32) for s in (0, 1, 2)]
+    kw = dict(n_grid=32, grid_lim=scs[0]["grid_lim"], dt=scs[0]["dt"], n_substeps=substeps, params=scs[0]["params"], min_bounds=scs[0]["min_bounds"],
+              max_bounds=scs[0]["max_bounds"], to_field_frame=lambda x: (x - 1.0) * scs[0]["field_scale"], configure=lambda s: s.add_bounding_box(),
+              ranges=scs[0]["ranges"])
+    dev_scene = lambda sc: (torch.from_numpy(sc["feat"]).to(hip_device), torch.from_numpy(sc["mask"]).to(hip_device),
+                            torch.from_numpy(sc["x"]).to(hip_device), torch.from_numpy(sc["vol"]).to(hip_device))
+    batch = neural_scene_batch(seg, cont, (dev_scene(sc) for sc in scs), **kw)
+    xs = [b.export_particle_x_to_torch().clone() for b in batch]       # on the current stream: ordered after every rollout
+    for sc, b, x in zip(scs, batch, xs):
+        a, _, _ = neural_scene_rollout(seg, cont, *dev_scene(sc), **kw)
+        assert torch.equal(x, a.export_particle_x_to_torch())
+        for f in ("v", "C", "F_trial", "material", "E"):
+            assert torch.equal(a.get_field(f), b.get_field(f)), f
+        assert float((x.cpu() - torch.from_numpy(sc["x"])).norm()) > 0
