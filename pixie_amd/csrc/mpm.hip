@@ -84,6 +84,7 @@ struct StepParams {
     float damping;
     int do_damping;
     float rpic;
+    int xcd_order;  // set_scalar "xcd_order": work items dealt to the XCDs in contiguous runs (see mpm_block_kernel)
     int comp_x;     // set_scalar "compensated_x": carry the rounding error of x += dt v in xlo (see particle_phase1)
     int trace;      // timing studies: bit 0 = workgroups stamp s_memrealtime around their phases into g_mpm_trace;
                     // bits 8.. = ablations for bottleneck hunting (RESULTS ARE WRONG with any of them set):
@@ -631,7 +632,16 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
     __shared__ unsigned long long ta[PACK ? 2 : 4][kTN];  // (m*v.xyz, m) of this work item as scaled integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
-    const int4 it = S.items[blockIdx.x];
+    // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and each XCD has its own L2.  The work list is in
+    // block order, so with sp.xcd_order every XCD takes a CONTIGUOUS eighth of it: neighbouring blocks -- whose 8^3 tiles of gout
+    // overlap eightfold -- then share their staging reads in that XCD's L2 instead of fetching them once per XCD
+    // (set_scalar "xcd_order"; the tile a work item publishes is addressed by the item, not by the workgroup).
+    int item = (int)blockIdx.x;
+    if (sp.xcd_order) {
+        const int per = (int)gridDim.x >> 3;
+        if (item < (per << 3)) item = (item & 7) * per + (item >> 3);      // (the last n % 8 items keep their place)
+    }
+    const int4 it = S.items[item];
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;   // = the work-item capacity of the current binning (256; 128 on request)
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
@@ -764,7 +774,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
     PX_MPM_STAMP(4);
     const float iP = pow2_reciprocal(sP), iM = pow2_reciprocal(sM);
     // ---- publish the tile: coalesced stores; the grid update sums the tiles that cover each node ----
-    float4* dst = S.part + (size_t)blockIdx.x * kTN;
+    float4* dst = S.part + (size_t)item * kTN;
     if (!(TRACE && (sp.trace & 0x800)))
         for (int idx = tid; idx < kTN; idx += nthr) {
             float4 o;
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
             const bool nz = (o.x != 0.0f) | (o.y != 0.0f) | (o.z != 0.0f) | (o.w != 0.0f);
             if (S.sparse_tiles) {
                 const unsigned long long live = __ballot(nz);     // lanes of a wave hold 64 consecutive nodes
-                if ((tid & 63) == 0) S.tile_mask[(size_t)blockIdx.x * 8 + (idx >> 6)] = live;
+                if ((tid & 63) == 0) S.tile_mask[(size_t)item * 8 + (idx >> 6)] = live;
                 if (nz) dst[si] = o;
             } else {
                 dst[si] = o;
@@ -1495,6 +1505,7 @@ struct pixie_mpm {
     int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
     int comp_x = 0;                          // set_scalar "compensated_x"
+    int xcd_order = 0;                       // set_scalar "xcd_order"
     bool pmods_were_active = false;
     float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
     unsigned long long* tile_mask = nullptr; // [max_items][8] occupancy bits of the staged tiles
@@ -1651,6 +1662,7 @@ StepParams make_params(const pixie_mpm* h, double dt, double time) {
     sp.rpic = h->rpic;
     sp.trace = h->trace;
     sp.comp_x = h->comp_x;
+    sp.xcd_order = h->xcd_order;
     sp.ms = h->ms;
     return sp;
 }
@@ -2097,6 +2109,7 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
     else if (k == "trace") h->trace = (int)value;
 #endif
     else if (k == "compensated_x") h->comp_x = value != 0.0 ? 1 : 0;
+    else if (k == "xcd_order") h->xcd_order = value != 0.0 ? 1 : 0;
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
     else if (k == "item_cap") { PX_REQUIRE(value == 0 || value == 64 || value == 128 || value == 192 || value == 256, "item_cap must be 0 (auto), 64, 128, 192 or 256"); h->item_cap_user = (int)value; h->needs_sort = true; }
     else if (k == "resort_interval") { h->resort_interval = (int)value; h->resort_auto = false; }   // substeps between re-binnings (0 = only when positions are replaced)

@@ -44,7 +44,7 @@ def main():
         s._set_scalar("occupancy", int(os.environ["PIXIE_MPM_OCC"]))
     if os.environ.get("PIXIE_MPM_ITEM_CAP"):
         s._set_scalar("item_cap", int(os.environ["PIXIE_MPM_ITEM_CAP"]))
-    for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb")):
+    for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb"), ("PIXIE_MPM_XCD", "xcd_order")):
         if os.environ.get(env):
             s._set_scalar(key, int(os.environ[env]))
     if os.environ.get("PIXIE_MPM_V0"):     # a scene in motion: random particle velocities of this rms per component (strains of a few %)

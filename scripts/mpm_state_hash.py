@@ -18,10 +18,12 @@ s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["v
 apply_scene(s, sc)
 if len(sys.argv) > 4:
     s._set_scalar("scatter_bits", int(sys.argv[4]))
+if os.environ.get("PIXIE_MPM_XCD"):
+    s._set_scalar("xcd_order", int(os.environ["PIXIE_MPM_XCD"]))
 g = torch.Generator().manual_seed(1)
 s.import_particle_v_from_torch(0.6 * torch.randn((n, 3), generator=g))
 s.run(sc["dt"], steps)
 h = hashlib.sha256()
 for f in ("x", "v", "C", "F_trial"):
     h.update(s.get_field(f).cpu().numpy().tobytes())
-print(f"n={n} ng={ng} substeps={steps} bits={sys.argv[4] if len(sys.argv) > 4 else 'dflt'} rebins={int(s._get_scalar('n_rebins'))} sha256={h.hexdigest()[:32]}")
+print(f"xcd_order={os.environ.get('PIXIE_MPM_XCD', 'dflt')} n={n} ng={ng} substeps={steps} bits={sys.argv[4] if len(sys.argv) > 4 else 'dflt'} rebins={int(s._get_scalar('n_rebins'))} sha256={h.hexdigest()[:32]}")
