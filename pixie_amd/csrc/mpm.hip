@@ -523,7 +523,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
 // undoes exactly that, so the two sums are exact integers and order-independent like the 64-bit ones.  What changes is the
 // quantum: 2^-30 of the SUM of the contribution bounds of the tile's particles instead of 2^-42 of their maximum -- the
 // order of the fp32 atomics of the reference (2^-24 of each partial sum) for nodes that carry mass, but a node whose whole
-// mass is below ~1e-7 of a particle's (stencil corners at a free surface) is quantised visibly: see DESIGN.md 3.5 and
+// mass is below ~1e-7 of a particle's (stencil corners at a free surface) is quantised visibly: see HISTORY.md 3.5 and
 // tests/test_mpm_hip.py::test_packed_scatter_parity.
 constexpr double kMagicD = 6755399441055744.0;            // 1.5 * 2^52
 
