@@ -1021,10 +1021,13 @@ def compact_line(d, detail_path=None):
         line["mpm_1m_2_scenes_frac_touched"] = _r(two["frac_touched_cells"])
         line["mpm_1m_2_scenes_frac_dense"] = _r(two["frac_dense_grid"])
     for name, mp in ((d.get("mpm_1m") or {}).get("plastic") or {}).items():
+        # SURVEY 8f-4 "plastic materials at scale": top-level scalars per leg (the reference's sand / snow / metal configs, a mixed scene)
         ctr = mp.get("counters") or {}
-        line[f"mpm_1m_{name}"] = {"us_per_substep": _r(mp["us_per_substep"]), "frac_dense": _r(mp["frac_dense_grid"]), "frac_touched": _r(mp["frac_touched_cells"]),
-                                  "block_kernel_us": mp["block_kernel_us"], "vs_jelly": _r(mp["vs_jelly_1m_substep"], 3),
-                                  "valu_per_wave": ctr.get("valu_per_wave"), "block_kernel_us_rocprofv3": ctr.get("block_kernel_us")}
+        pre = f"mpm_1m_{name}"
+        line[pre + "_us_per_substep"] = _r(mp["us_per_substep"])
+        line[pre + "_frac_dense"], line[pre + "_frac_touched"] = _r(mp["frac_dense_grid"], 3), _r(mp["frac_touched_cells"], 3)
+        line[pre + "_vs_jelly"] = _r(mp["vs_jelly_1m_substep"], 3)
+        line[pre + "_block_us_rocprofv3"], line[pre + "_valu_per_wave"] = ctr.get("block_kernel_us"), ctr.get("valu_per_wave")
     jc = (d.get("mpm_1m") or {}).get("counters") or {}
     if jc:
         line["mpm_1m_valu_per_wave"], line["mpm_1m_block_kernel_us_rocprofv3"] = jc.get("valu_per_wave"), jc.get("block_kernel_us")
@@ -1183,7 +1186,8 @@ def main():
         line = compact_line(detail, path)
         text = json.dumps(line)
         # the driver's record keeps ~6 KB of the line: drop optional keys (they stay in the detail file) rather than lose the run
-        for key in ("telemetry", "exact_f32", "mpm_cpu_baseline", "mpm_1m_cpu_baseline", "mpm_1m_kernel", "mpm_kernel", "mpm_1m_mixed", "mpm_1m_snow"):
+        for key in ("telemetry", "exact_f32", "mpm_cpu_baseline", "mpm_1m_cpu_baseline", "mpm_1m_kernel", "mpm_kernel", "pipeline_parts_ms",
+                    "mpm_1m_in_motion_us_per_substep", "mpm_1m_in_motion_frac_touched", "p2g2p_loop_vs_run", "mpm_exact_scatter_us_per_substep"):
             if len(text) < 6144:
                 break
             if line.pop(key, None) is not None:
