@@ -914,8 +914,8 @@ __device__ __forceinline__ int cell_in_block(const MpmPtrs& S, int p) {
 // Material class of a particle for the ordering inside a block: the constitutive branches of return_map_and_stress.  A block
 // that mixes materials (material_mode=neural uploads an id per particle, PG/material_field.py:343-363) is laid out class by
 // class, round-robin by cell inside a class, so that a wave runs ONE branch instead of all of them (mixed 1 M scene: 1955 -> 1600
-// VALU instructions per wave, 82.9 -> 78.5 us per substep = the single-material plastic scenes' 78.2; profiles/r5d_*); a single-material block -- every block of a single-material scene -- keeps the
-// order it always had.
+// VALU instructions per wave, 82.9 -> 78.5 us per substep = the single-material plastic scenes' 78.2; profiles/r5d_*); a
+// single-material block -- every block of a single-material scene -- keeps the order it always had.
 constexpr int kMatClasses = 7;
 __device__ __forceinline__ int material_class(int material) {
     return material == 0 ? 0 : material == 1 ? 1 : material == 2 ? 2 : material == 3 ? 3 : material == 5 ? 4 : material == 6 ? 5 : 6;
