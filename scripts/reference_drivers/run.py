@@ -403,6 +403,15 @@ def _part_e_worker(rank, world, cfg_dict, seg_ckpt, cont_ckpt, out_dir, port):
     R.get_obj_class_for_id = lambda obj_id, cfg: "tree"
     R.load_json = lambda p: json.load(open(p))
     S.DDP_BACKEND, S.DDP_PORT = "gloo", str(port)
+    if torch.cuda.device_count() < world:
+        # The reference uses the process rank as the device ordinal (`torch.cuda.set_device(rank)`, `.to(rank)`); this box shows fewer
+        # devices than ranks, so THE RUNNER maps every integer device ordinal to device 0 -- the ranks share the one GPU.  Everything
+        # else (rendezvous, DistributedSampler split, per-rank DataLoader, gather_object, rank 0's report) is the reference's own code.
+        _set_device, _t_to, _m_to = torch.cuda.set_device, torch.Tensor.to, torch.nn.Module.to
+        fix = lambda a: tuple(0 if (isinstance(x, int) and not isinstance(x, bool)) else x for x in a)
+        torch.cuda.set_device = lambda d: _set_device(0)
+        torch.Tensor.to = lambda self, *a, **k: _t_to(self, *fix(a), **k)
+        torch.nn.Module.to = lambda self, *a, **k: _m_to(self, *fix(a), **k)
     S.run_inference_on_gpu(rank, world, NCfg(cfg_dict), seg_ckpt, cont_ckpt, None, out_dir, print_table=False)   # verbatim :229-288
 
 
@@ -410,8 +419,9 @@ def part_e(root, D, C, world):
     """run_inference_on_gpu (inference_combined.py:229-288) verbatim -- ddp_setup, load_normalization_ranges, load_test_dataset,
     DistributedSampler(shuffle=False), DataLoader(pin_memory), create_models, load_checkpoint, process_batch per batch,
     InferenceMetrics.gather_all_metrics (dist.gather_object), generate_metrics_report on rank 0 -- as `world` processes started with
-    torch.multiprocessing.spawn, on gloo (the reference's "nccl" cannot form two ranks on this box's single GPU; its
-    rank == device-ordinal convention needs `world` visible devices: the session script exposes the GPU twice when it can).
+    torch.multiprocessing.spawn, on gloo (the reference's "nccl" cannot form two ranks on this box's single GPU).  Its
+    rank == device-ordinal convention needs `world` visible devices; with fewer, the runner maps integer device ordinals to
+    device 0 inside the workers (the ranks share the GPU) -- the only thing emulated.
     Checks: every object's four files exist exactly once, they equal a single-process run over the same objects bit for bit,
     rank 0's report lists every object."""
     import torch.multiprocessing as mp
@@ -444,7 +454,8 @@ def part_e(root, D, C, world):
         mp.spawn(_part_e_worker, args=(w, json.loads(json.dumps(cfg)), ckpts[0], ckpts[1], out_dir, port), nprocs=w, join=True)
         outs[w] = out_dir
         files = sorted(os.listdir(out_dir))
-        say(f"E. run_inference_on_gpu verbatim, world_size {w} (mp.spawn, gloo, {torch.cuda.device_count()} visible device(s)): {time.perf_counter() - t0:.1f} s; {files}")
+        shared = " -- the ranks SHARE the one GPU: the runner maps integer device ordinals to 0" if torch.cuda.device_count() < w else ""
+        say(f"E. run_inference_on_gpu verbatim, world_size {w} (mp.spawn, gloo, {torch.cuda.device_count()} visible device(s){shared}): {time.perf_counter() - t0:.1f} s; {files}")
         ev = json.load(open(os.path.join(out_dir, "evaluated_obj_ids.json")))
         assert ev == obj_ids, ev
         assert any(f.startswith("metrics") or f.endswith("metrics.json") for f in files) or len(files) >= len(obj_ids) + 2, files
@@ -478,7 +489,7 @@ def main():
     if "d" in a.only:
         part_d(a.gaussians)
     if "e" in a.only:
-        part_e(root, min(a.grid, 32), a.channels, min(a.world, torch.cuda.device_count()))
+        part_e(root, min(a.grid, 32), a.channels, a.world)
     say("ALL CHECKS PASSED")
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     open(os.path.join(REPO, "gpurun_out", "reference_drivers.log"), "w").write("\n".join(LOG) + "\n")
