@@ -180,7 +180,10 @@ def pin_rank_resources(rank, world):
     which would make the CPU-side set-up of every rank single-threaded) and keep the ranks off each other's cores."""
     cores = os.cpu_count() or 1
     if world <= 1:
-        return torch.get_num_threads()      # what the CPU legs actually run on (torch's default: the physical cores)
+        q = cpu_quota()
+        if q and q < torch.get_num_threads():
+            torch.set_num_threads(max(1, int(round(q))))     # the container's CPU quota, not the host's core count
+        return torch.get_num_threads()      # what the CPU legs actually run on
     share = max(1, cores // world)
     try:
         avail = sorted(os.sched_getaffinity(0))
