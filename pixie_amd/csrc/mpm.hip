@@ -861,8 +861,10 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const int* __restrict__ 
     const int tid = threadIdx.x;
     const int per = (nblocks + 1023) / 1024;
     const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
-    int csum = 0, isum = 0;
-    for (int b = b0; b < b1; ++b) { const int c = counts[b]; csum += c; isum += (c + cap - 1) / cap; }
+    int csum = 0, isum = 0, iother = 0;
+    const int other = (cap == kWG) ? kWG / 2 : kWG;     // how many items the other capacity would make (auto item_cap, see rebin())
+    for (int b = b0; b < b1; ++b) { const int c = counts[b]; csum += c; isum += (c + cap - 1) / cap; iother += (c + other - 1) / other; }
+    if (iother) atomicAdd(&n_items[3], iother);
     s_cnt[tid] = csum; s_itm[tid] = isum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -1505,6 +1507,7 @@ struct pixie_mpm {
     int occupancy = 5;                       // register-allocation target of the fused kernel (waves per SIMD): 5 or 6
     int item_cap = kWG;                      // particles per work item of the current binning: 128 or 256
     int item_cap_user = 0;                   // set_scalar "item_cap": 0 = automatic
+    bool auto_half_items = false;            // item_cap "auto": 128-thread work items from the next re-binning on (see rebin())
     int comp_x = 0;                          // set_scalar "compensated_x"
     int xcd_order = 1;                       // set_scalar "xcd_order" (on: 63.5 -> 61.9 us per substep at 1 M, 18.0 -> 17.5 at 100 k, same bits; profiles/r5g_xcd_order.txt)
     bool pmods_were_active = false;
@@ -1575,7 +1578,12 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     // Work-item capacity: 256 particles (one per thread).  128-thread items were measured too (set_scalar "item_cap"):
     // 100 k particles 21.0 -> 23.8 us per launch (916 items instead of 526: the per-item tile staging / barriers /
     // publish dominate), 1 M particles 100 -> 95 us but the grid kernel pays for twice the tiles (14.8 -> 20.7 us).
-    h->item_cap = h->item_cap_user > 0 ? h->item_cap_user : kWG;
+    // Automatic: 128-thread items in scenes so sparse that almost no block holds more than 128 particles -- there a 256-thread
+    // workgroup runs two waves without a particle (the reference's sand configuration at 1 M: 121 -> 111 us per substep) -- and
+    // 256 everywhere else (1 M in 120^3: 62.5 vs 70.9 us; 100 k in 50^3: 17.5 vs 21.8; profiles/r5e_item_cap_sparse_scenes.txt).
+    // Decided from the counts of the PREVIOUS re-binning (both item counts come back with it): see the end of this function.
+    h->item_cap = h->item_cap_user > 0 ? h->item_cap_user : (h->auto_half_items ? kWG / 2 : kWG);
+    PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 3, 0, sizeof(int), st));
     PX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->nblocks * sizeof(int), st));
     PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 2, 0, sizeof(int), st));
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts,
@@ -1599,7 +1607,7 @@ int rebin(pixie_mpm* h, hipStream_t st) {
         hipLaunchKernelGGL(mass_range_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->d_mass_range);
         PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 6, h->d_mass_range, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
-    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 4, h->S.oob + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 8, h->S.oob, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items + 10, h->S.oob + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1611,6 +1619,11 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
+    {   // half-size work items from the next re-binning on iff they would be (almost) as few as full-size ones: < 3 % more
+        const long other = h->h_n_items[3];
+        const long n256 = (h->item_cap == kWG) ? h->n_items : other, n128 = (h->item_cap == kWG) ? other : h->n_items;
+        if (h->item_cap == kWG || h->item_cap == kWG / 2) h->auto_half_items = n128 * 100 <= n256 * 103;
+    }
     if (measure_mass) {
         float lo, hi;
         memcpy(&lo, h->h_n_items + 6, sizeof lo); memcpy(&hi, h->h_n_items + 7, sizeof hi);
@@ -2129,6 +2142,7 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "grid_v_damping_scale") *value = h->damping;
     else if (k == "resort_interval") *value = h->resort_interval;
     else if (k == "n_work_items") *value = h->n_items;
+    else if (k == "item_cap") *value = h->item_cap;                    // the capacity in force (as of the last re-binning when auto)
     else if (k == "scatter_bits") *value = h->scatter_bits;            // the mode in force (as of the last re-binning when auto)
     else if (k == "scatter_bits_user") *value = h->scatter_bits_user;
     else if (k == "mass_contrast") *value = h->mass_contrast;

@@ -66,7 +66,7 @@ def main():
         p_ms, g_ms, nl = s.kernel_times()
         s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
-    print(f"n={n} ng={ng} resort={resort} {scenario} lib={'diag' if diag else 'product'} occ={os.environ.get('PIXIE_MPM_OCC', '5')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', '256')} "
+    print(f"n={n} ng={ng} resort={resort} {scenario} lib={'diag' if diag else 'product'} occ={os.environ.get('PIXIE_MPM_OCC', '5')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', 'auto')}->{int(s._get_scalar('item_cap'))} "
           f"bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} v0={os.environ.get('PIXIE_MPM_V0', '0')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (max(p_ms, 1e-9) * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "

@@ -931,6 +931,25 @@ def test_full_size_mixed_material_scene_properties(hip_device):
     assert np.array_equal(get(h2, "x"), x) and np.array_equal(get(h2, "F_trial"), F)
 
 
+def test_work_item_capacity_follows_the_scene_density(hip_device):
+    """item_cap "auto": 256-thread work items in dense scenes, 128-thread ones from the second re-binning on where almost no block
+    holds more than 128 particles (a 256-thread workgroup then runs two waves without a particle); a forced capacity stays; and
+    the choice changes work-item composition only -- the trajectory stays within packed-scatter quantisation of the other choice."""
+    dense = make_hip(mpm_ball_scene(100_000, seed=2))                      # 100 k in 50^3: ~190 particles per occupied block
+    dense.run(1e-4, 40)
+    assert int(dense._get_scalar("item_cap")) == 256 and int(dense._get_scalar("n_rebins")) >= 2
+    sc = mpm_ball_scene(100_000, seed=2, n_grid=160)                       # the same particles in 160^3: ~10 per occupied block
+    sparse, forced = make_hip(sc), make_hip(sc)
+    forced._set_scalar("item_cap", 256)
+    sparse.run(sc["dt"], 40); forced.run(sc["dt"], 40)
+    assert int(sparse._get_scalar("item_cap")) == 128 and int(forced._get_scalar("item_cap")) == 256
+    assert int(sparse._get_scalar("n_work_items")) <= 1.03 * int(forced._get_scalar("n_work_items"))
+    for f in ("x", "F_trial"):
+        assert rel_l2(get(sparse, f), get(forced, f)) < 1e-6, f
+    assert rel_l2(get(sparse, "v"), get(forced, "v")) < 1e-4
+    assert sparse.out_of_bounds == 0
+
+
 def test_export_frame_for_rendering(hip_device):
     """gs_simulation.py:591-600 in one launch, against tests/golden/frame_export.npz: the REFERENCE's own
     transformation_utils.py / material_field.py:81-86 functions (executed via `ast`, tests/golden/make_frame_export_golden.py)
