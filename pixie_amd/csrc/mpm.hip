@@ -1578,8 +1578,8 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     // Work-item capacity: 256 particles (one per thread).  128-thread items were measured too (set_scalar "item_cap"):
     // 100 k particles 21.0 -> 23.8 us per launch (916 items instead of 526: the per-item tile staging / barriers /
     // publish dominate), 1 M particles 100 -> 95 us but the grid kernel pays for twice the tiles (14.8 -> 20.7 us).
-    // Automatic: 128-thread items in scenes so sparse that almost no block holds more than 128 particles -- there a 256-thread
-    // workgroup runs two waves without a particle (the reference's sand configuration at 1 M: 121 -> 111 us per substep) -- and
+    // Automatic: 128-thread items in scenes so sparse that few blocks hold more than 128 particles -- there a 256-thread
+    // workgroup runs two waves without a particle (the reference's sand configuration at 1 M: 120 -> 108 us per substep) -- and
     // 256 everywhere else (1 M in 120^3: 62.5 vs 70.9 us; 100 k in 50^3: 17.5 vs 21.8; profiles/r5e_item_cap_sparse_scenes.txt).
     // Decided from the counts of the PREVIOUS re-binning (both item counts come back with it): see the end of this function.
     h->item_cap = h->item_cap_user > 0 ? h->item_cap_user : (h->auto_half_items ? kWG / 2 : kWG);
@@ -1619,10 +1619,12 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
-    {   // half-size work items from the next re-binning on iff they would be (almost) as few as full-size ones: < 3 % more
+    {   // half-size work items from the next re-binning on iff they would be nearly as few as full-size ones: <= 10 % more.
+        // (Break-even measured near +20 %: 1 M jelly in 200^3, +22 % items, 89.6 vs 90.6 us; the sand configuration, +2 ... 8 % over its
+        // run, 120 -> 108 us; dense scenes, +64 ... 74 % items, lose 13 %.  profiles/r5e_item_cap_sparse_scenes.txt)
         const long other = h->h_n_items[3];
         const long n256 = (h->item_cap == kWG) ? h->n_items : other, n128 = (h->item_cap == kWG) ? other : h->n_items;
-        if (h->item_cap == kWG || h->item_cap == kWG / 2) h->auto_half_items = n128 * 100 <= n256 * 103;
+        if (h->item_cap == kWG || h->item_cap == kWG / 2) h->auto_half_items = n128 * 100 <= n256 * 110;
     }
     if (measure_mass) {
         float lo, hi;
