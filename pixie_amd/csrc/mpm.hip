@@ -1619,12 +1619,12 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
-    {   // half-size work items from the next re-binning on iff they would be nearly as few as full-size ones: <= 10 % more.
+    {   // half-size work items from the next re-binning on iff they would be nearly as few as full-size ones: <= 15 % more.
         // (Break-even measured near +20 %: 1 M jelly in 200^3, +22 % items, 89.6 vs 90.6 us; the sand configuration, +2 ... 8 % over its
         // run, 120 -> 108 us; dense scenes, +64 ... 74 % items, lose 13 %.  profiles/r5e_item_cap_sparse_scenes.txt)
         const long other = h->h_n_items[3];
         const long n256 = (h->item_cap == kWG) ? h->n_items : other, n128 = (h->item_cap == kWG) ? other : h->n_items;
-        if (h->item_cap == kWG || h->item_cap == kWG / 2) h->auto_half_items = n128 * 100 <= n256 * 110;
+        if (h->item_cap == kWG || h->item_cap == kWG / 2) h->auto_half_items = n128 * 100 <= n256 * 115;
     }
     if (measure_mass) {
         float lo, hi;

@@ -933,7 +933,7 @@ def test_full_size_mixed_material_scene_properties(hip_device):
 
 def test_work_item_capacity_follows_the_scene_density(hip_device):
     """item_cap "auto": 256-thread work items in dense scenes, 128-thread ones from the second re-binning on where few blocks
-    hold more than 128 particles (<= 10 % more work items) (a 256-thread workgroup then runs two waves without a particle); a forced capacity stays; and
+    hold more than 128 particles (<= 15 % more work items) (a 256-thread workgroup then runs two waves without a particle); a forced capacity stays; and
     the choice changes work-item composition only -- the trajectory stays within packed-scatter quantisation of the other choice."""
     dense = make_hip(mpm_ball_scene(100_000, seed=2))                      # 100 k in 50^3: ~190 particles per occupied block
     dense.run(1e-4, 40)
@@ -943,7 +943,7 @@ def test_work_item_capacity_follows_the_scene_density(hip_device):
     forced._set_scalar("item_cap", 256)
     sparse.run(sc["dt"], 40); forced.run(sc["dt"], 40)
     assert int(sparse._get_scalar("item_cap")) == 128 and int(forced._get_scalar("item_cap")) == 256
-    assert int(sparse._get_scalar("n_work_items")) <= 1.10 * int(forced._get_scalar("n_work_items"))
+    assert int(sparse._get_scalar("n_work_items")) <= 1.15 * int(forced._get_scalar("n_work_items"))
     for f in ("x", "F_trial"):
         assert rel_l2(get(sparse, f), get(forced, f)) < 1e-6, f
     assert rel_l2(get(sparse, "v"), get(forced, "v")) < 1e-4
