@@ -207,3 +207,31 @@ def test_pack_kernel_writes_the_wire_format_of_the_host_path(hip_device, n, shap
     if n > 1:     # a contiguous view at an offset that is not a multiple of 16 bytes (odd voxel count): copied before the 16-byte moves
         dc, ds = cont.to(hip_device), seg.to(hip_device)
         assert torch.equal(pd.pack_fields(dc[1:], ds[1:]).cpu(), pd.pack_fields(cont[1:], seg[1:]))
+
+
+def test_bench_line_of_a_full_run_fits_the_drivers_record():
+    """The compact line bench.py prints (the driver keeps ~6 KB of it) rendered from the committed full record of the closing
+    session: every contract key is there, `roofline` and `cpu_baseline` carry their fields, the plastic legs are top-level scalars,
+    and the whole line stays under 6 KB."""
+    import importlib.util
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(repo, "profiles", "bench_detail_r5last.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed bench detail")
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    line = bench.compact_line(json.load(open(path)), "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 6144, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert line["vs_baseline"] is None and "workload" in line["config"]
+    for leg in ("sand", "snow", "metal", "mixed"):
+        for f in ("us_per_substep", "frac_dense", "frac_touched", "valu_per_wave", "block_us_rocprofv3"):
+            assert isinstance(line[f"mpm_1m_{leg}_{f}"], (int, float)), (leg, f)
+    for k in ("mpm_floor_us", "mpm_frac_of_floor", "pipeline_ms_per_scene", "mpm_1m_frac_touched", "mpm_1m_frac_dense"):
+        assert isinstance(line[k], (int, float)), k
