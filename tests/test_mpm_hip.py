@@ -931,6 +931,32 @@ def test_full_size_mixed_material_scene_properties(hip_device):
     assert np.array_equal(get(h2, "x"), x) and np.array_equal(get(h2, "F_trial"), F)
 
 
+def test_tiny_and_degenerate_scenes(hip_device):
+    """Edge cases of the particle set: one particle, two particles in one cell, a handful spread over distant blocks, every particle
+    frozen (selection = 1: the reference's kernels skip it everywhere), zero substeps -- each against the float64 oracle (or the
+    exact no-op it must be)."""
+    from pixie_amd.mpm_solver import MPM_Simulator_WARP
+    base = mpm_ball_scene(64, seed=12, scenario="ball")
+    for tag, idx in (("one particle", [0]), ("two in one cell", [0, 0]), ("five far apart", [0, 9, 17, 33, 60])):
+        sc = {k: (v[idx].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (64,) else v) for k, v in base.items()}
+        if tag == "two in one cell":
+            sc["x"][1] = sc["x"][0] + np.float32(1e-3)
+        h, o = make_hip(sc), make_oracle(sc, "f64")
+        h.run(sc["dt"], 0)                                    # nothing to do
+        assert np.array_equal(get(h, "x"), sc["x"]) and h.time == 0.0
+        h.run(sc["dt"], 30); o.run(sc["dt"], 30)
+        ex, ev = rel_l2(get(h, "x"), o.field("x")), rel_l2(get(h, "v"), o.field("v"))
+        print(f"{tag}: x {ex:.1e} v {ev:.1e} after 30 substeps of free fall")
+        assert ex < 1e-6 and ev < 1e-4 and h.out_of_bounds == 0
+        assert abs(float(get(h, "v")[0, 2]) + 9.8 * 30 * sc["dt"]) < 1e-4      # g t (the walls are far away)
+    sc = dict(base)
+    h = make_hip(sc)
+    h.set_field("selection", np.ones(64, np.int32))
+    h.run(sc["dt"], 20)
+    assert np.array_equal(get(h, "x"), sc["x"]) and float(np.abs(get(h, "v")).max()) == 0.0
+    assert np.isfinite(h.get_field("grid_v_out").cpu().numpy()).all()
+
+
 def test_work_item_capacity_follows_the_scene_density(hip_device):
     """item_cap "auto": 256-thread work items in dense scenes, 128-thread ones from the second re-binning on where few blocks
     hold more than 128 particles (<= 15 % more work items) (a 256-thread workgroup then runs two waves without a particle); a forced capacity stays; and
