@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, bench, rocprofv3 kernel stats.  Everything lands in gpurun_out/.
-# usage: scripts/gpu_session.sh [tag]
+# usage: scripts/sessions/gpu_session.sh [tag]
 TAG=${1:-r1}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
