@@ -303,6 +303,10 @@ typedef struct {
     real grid_lim, dx, inv_dx;
     /* MPMStateStruct, warp_utils.py:42-74 */
     real *x, *v, *F, *F_trial, *C, *stress, *vol, *mass, *density;
+#ifdef ORACLE_EXPERIMENT   /* tests/golden/attribute_config3_drift.py only: bit 0 = positions, bit 1 = deformation gradients carried in double */
+    double *xd, *Fd, *Ftd;
+    int exp_init;
+#endif
     int *material, *selection;
     real *grid_m, *grid_v_in, *grid_v_out;
     /* MPMModelStruct, warp_utils.py:6-39 */
@@ -683,6 +687,13 @@ void mpm_compute_stress(MPM *s, double dt_d) {
         else if (material == 3) rm_visco(s, p, Ft, dt, F);
         else if (material == 5) rm_von_mises(s, p, Ft, F, 1);
         else memcpy(F, Ft, 9 * sizeof(real));
+#ifdef ORACLE_EXPERIMENT
+        if ((ORACLE_EXPERIMENT & 2) && s->exp_init) {   /* F = returnMap(F_trial): the double copy follows (exactly, where F = F_trial) */
+            int same = 1;
+            for (int i = 0; i < 9; ++i) same = same && (F[i] == Ft[i]);
+            for (int i = 0; i < 9; ++i) s->Fd[9 * p + i] = same ? s->Ftd[9 * p + i] : (double)F[i];
+        }
+#endif
         real J = m_det(F);
         real U[9], V[9], sig[3], st[9];
         memset(st, 0, sizeof st);
@@ -892,6 +903,15 @@ void mpm_apply_bcs(MPM *s, double dt_d) {
 /* g2p, mpm_utils.py:412-463 (update_cov_with_F is always False in the reference flows) */
 void mpm_g2p(MPM *s, double dt_d) {
     real dt = P_(dt_d);
+#ifdef ORACLE_EXPERIMENT
+    if (!s->exp_init) {
+        const size_t N = (size_t)s->n;
+        s->xd = malloc(3 * N * sizeof(double)); s->Fd = malloc(9 * N * sizeof(double)); s->Ftd = malloc(9 * N * sizeof(double));
+        for (size_t i = 0; i < 3 * N; ++i) s->xd[i] = (double)s->x[i];
+        for (size_t i = 0; i < 9 * N; ++i) { s->Fd[i] = (double)s->F[i]; s->Ftd[i] = (double)s->F_trial[i]; }
+        s->exp_init = 1;
+    }
+#endif
     OMP_FOR
     for (int p = 0; p < s->n; ++p) {
         if (s->selection[p] != 0) continue;
@@ -928,6 +948,17 @@ void mpm_g2p(MPM *s, double dt_d) {
         real A[9];
         for (int i = 0; i < 9; ++i) A[i] = ((i % 4 == 0) ? R_(1.0) : R_(0.0)) + nF[i] * dt;
         m_mul(A, s->F + 9 * p, s->F_trial + 9 * p);
+#ifdef ORACLE_EXPERIMENT
+        if (ORACLE_EXPERIMENT & 1)      /* x = the float rounding of a position accumulated in double (the same float32 v) */
+            for (int d = 0; d < 3; ++d) { s->xd[3 * p + d] += (double)dt * (double)nv[d]; s->x[3 * p + d] = (real)s->xd[3 * p + d]; }
+        if (ORACLE_EXPERIMENT & 2) {    /* F_trial = the float rounding of (I + dt grad v) F accumulated in double (the same float32 grad v) */
+            double Ad[9], Td[9];
+            for (int i = 0; i < 9; ++i) Ad[i] = ((i % 4 == 0) ? 1.0 : 0.0) + (double)nF[i] * (double)dt;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Td[3 * i + j] = Ad[3 * i] * s->Fd[9 * p + j] + Ad[3 * i + 1] * s->Fd[9 * p + 3 + j] + Ad[3 * i + 2] * s->Fd[9 * p + 6 + j];
+            for (int i = 0; i < 9; ++i) { s->Ftd[9 * p + i] = Td[i]; s->F_trial[9 * p + i] = (real)Td[i]; }
+        }
+#endif
     }
 }
 

@@ -63,26 +63,14 @@ struct MpmPtrs {
     int *material, *selection, *perm;
     float* xref;                 // [3][n] positions at the last re-binning (drift measurement)
     float* xlo;                  // [3][n] what the float32 position leaves behind (compensated_x), see particle_phase1
-    float4 *gin, *gout;          // gin: where THIS launch's slow-path P2G adds (generation fl_w, see below)
+    float4 *gin, *gout;
     const int4* items;           // work list: (block id, first slot, count, 0)
     float4* part;                // [n_items][kTN]: (m*v.xyz, m) of each work item's tile, written by its P2G
     unsigned long long* tile_mask;  // [n_items][8]: bit t of a tile = "node t (tile coordinates, z fastest) is not all zero"
-    // What a grid update READS: the tiles of the P2G before it.  In the two-launch substep these are the arrays above; in the
-    // one-launch substep (F_CONSUME: the block kernel sums the previous P2G's tiles while it stages its own neighbourhood) the
-    // tiles are double-buffered -- a launch reads one copy and publishes into the other.
-    const float4* part_in;
-    const unsigned long long* mask_in;
-    // Slow-path P2G sums live in one of THREE generations of gin: a one-launch substep reads generation r (written by the launch
-    // before it), writes w = r + 1 and clears z = r - 1 -- which nobody reads or writes during this launch -- block by block where
-    // flagged.  blk_flags bit 1 + g = "generation g holds sums in this block".  (The two-launch substep stays on one generation: its
-    // grid kernel is the only reader and clears behind itself.)
-    float4 *gin_in, *gin_old;
-    int fl_w, fl_r, fl_z;
-    const int2* item_nbr;        // [n_items][32]: blk_items of the 27 neighbours of the item's block (lane q < 27), built at re-binning
     int sparse_tiles;            // 1: P2G stores only the non-zero nodes of a tile and the grid kernel reads only those (masks);
                                  // 0: whole tiles both ways (scenes too small to be bandwidth-bound: one dependent load fewer)
     const int2* blk_items;       // per block: (first work item, number of work items)
-    int* blk_flags;              // per block: bit 0 = active (particles nearby), bits 1..3 = slow-path particles wrote into that generation of gin here
+    int* blk_flags;              // per block: bit 0 = active (particles nearby), bit 1 = slow-path particles wrote into gin here
     const int* active_list;      // the active blocks
     const int2* nbr_table;       // per active block (same order): [0] = (block id, 0), [1..27] = blk_items of its 27 neighbours
     const unsigned* staged_lut;  // [256]: staged_index of tile nodes t (low half) and t + 256 (high half)
@@ -319,7 +307,7 @@ __device__ __noinline__ void g2p_gather_global(const float4* __restrict__ gout, 
     for (int q = 0; q < 9; ++q) { nv9[3 + q] = B[q]; nv9[12 + q] = G[q]; }
 }
 
-__device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int fl_w, int nbk, int ng, Stencil st,
+__device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int nbk, int ng, Stencil st,
                                                 const float* mvAT /* mv[3], A[9], T[9] */, float mass) {
     const size_t r0 = ((size_t)st.base[0] * ng + st.base[1]) * ng + st.base[2];
     // the 3x3x3 stencil touches at most 2 blocks per axis: tell the grid kernel they hold gin contributions.  The grid
@@ -329,7 +317,7 @@ __device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int
     bool reachable = true;
     for (int c = 0; c < 8; ++c) {
         const int bx = (st.base[0] + 2 * (c >> 2)) / kBS, by = (st.base[1] + 2 * ((c >> 1) & 1)) / kBS, bz = (st.base[2] + 2 * (c & 1)) / kBS;
-        reachable = reachable && (atomicOr(&blk_flags[(bx * nbk + by) * nbk + bz], fl_w) & 1);
+        reachable = reachable && (atomicOr(&blk_flags[(bx * nbk + by) * nbk + bz], 2) & 1);
     }
     if (!reachable) return false;
 #pragma unroll 1
@@ -349,244 +337,6 @@ __device__ __noinline__ bool p2g_scatter_global(float4* gin, int* blk_flags, int
         unsafeAtomicAdd(cell + 3, w * mass);
     }
     return true;
-}
-
-// ------------------------------------------------------------------ node update (grid kernel AND the one-launch block kernel)
-// grid_normalization_and_gravity (mpm_utils.py:398-409), add_damping_via_grid (:583-588) and the
-// BC `collide` closures (mpm_solver_warp.py:785-840 surface, :874-897 cuboid, :917-974 bounding box)
-// in one sweep; also re-zeroes (m*v, m) so the next P2G starts from a clean grid (zero_grid :295-300).
-// (No FMA contraction in apply_bc / finish_node: they are inlined into the grid kernel AND into the one-launch block kernel, and
-// whether `float(k) * dx - point` is fused decides on which side of a collider plane a node plane lies (tests: knife-edge scene).
-// Every operation rounded, as in the float32 oracle -- and therefore the same bits in every kernel they are inlined into.)
-__device__ __forceinline__ void apply_bc(const BCDev& b, int ix, int iy, int iz, int ng, float dx, float time,
-                                         float dt, float v[3]) {
-#pragma clang fp contract(off)
-    if (b.type == PIXIE_BC_SURFACE) {
-        if (time >= b.start && time < b.end) {
-            const float ox = (float)ix * dx - b.point[0], oy = (float)iy * dx - b.point[1], oz = (float)iz * dx - b.point[2];
-            const float dp = ox * b.normal[0] + oy * b.normal[1] + oz * b.normal[2];
-            if (dp < 0.0f) {
-                if (b.surface_type == 11) {
-                    if ((float)iz * dx < 0.4f || (float)iz * dx > 0.53f) {
-                        v[0] = v[1] = v[2] = 0.0f;
-                    } else {
-                        v[0] = v[0] * 0.3f; v[1] = 0.0f; v[2] = v[2] * 0.3f;
-                    }
-                } else {
-                    // sticky, and -- as in the reference (:821-840) -- slip/friction too: the projected
-                    // velocity is computed there but the store is zero.
-                    v[0] = v[1] = v[2] = 0.0f;
-                }
-            }
-        }
-    } else if (b.type == PIXIE_BC_CUBOID) {
-        if (time >= b.start && time < b.end) {
-            const float ox = (float)ix * dx - b.point[0], oy = (float)iy * dx - b.point[1], oz = (float)iz * dx - b.point[2];
-            if (fabsf(ox) < b.size[0] && fabsf(oy) < b.size[1] && fabsf(oz) < b.size[2]) {
-                v[0] = b.velocity[0]; v[1] = b.velocity[1]; v[2] = b.velocity[2];
-            }
-        } else if (b.reset == 1) {
-            if (time < b.end + 15.0f * dt) v[0] = v[1] = v[2] = 0.0f;
-        }
-    } else {
-        const int padding = 3;
-        if (time >= b.start && time < b.end) {
-            if (ix < padding && v[0] < 0.0f) v[0] = 0.0f;
-            if (ix >= ng - padding && v[0] > 0.0f) v[0] = 0.0f;
-            if (iy < padding && v[1] < 0.0f) v[1] = 0.0f;
-            if (iy >= ng - padding && v[1] > 0.0f) v[1] = 0.0f;
-            if (iz < padding && v[2] < 0.0f) v[2] = 0.0f;
-            if (iz >= ng - padding && v[2] > 0.0f) v[2] = 0.0f;
-        }
-    }
-}
-
-// (m*v, m) of node (gx,gy,gz) = what slow-path particles added to gin + the tiles of the work items that cover the node.
-// A node with g = 4m + r along an axis lies in the tiles of blocks {m-1, m} (r < 3) or {m, m+1} (r = 3) on that axis:
-// 8 candidate blocks per node, all among the 27 neighbours of the node's own block.  The wave first fetches the 27
-// (first item, count) pairs with one load (lane i < 27), then every lane walks its 8 candidates in rounds so that the
-// 8 tile loads of a round are in flight together.  The order of the sum is fixed; every staged value is read once.
-// lane i < 27 fetches (first item, count) of neighbour block i of block (Bx,By,Bz); other lanes get (0,0)
-__device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By, int Bz) {
-    const int lane = threadIdx.x & 63;
-    int2 mine = make_int2(0, 0);
-    if (lane < 27) {
-        const int bx = Bx + lane / 9 - 1, by = By + (lane / 3) % 3 - 1, bz = Bz + lane % 3 - 1;
-        if ((unsigned)bx < (unsigned)S.nbk && (unsigned)by < (unsigned)S.nbk && (unsigned)bz < (unsigned)S.nbk)
-            mine = S.blk_items[(bx * S.nbk + by) * S.nbk + bz];
-    }
-    return mine;
-}
-// One axis of staged_index: tile coordinate t -> (first node of its sub-box, nodes in the sub-box, t - first)
-__device__ __forceinline__ void staged_axis(int t, int& o, int& n, int& r) {
-    o = (t == 0) ? 0 : (t <= 4 ? 1 : 5);
-    n = (t == 0) ? 1 : (t <= 4 ? 4 : 3);
-    r = t - o;
-}
-// RB = items per candidate block fetched in one go (8 x RB tile loads in flight).
-// `mine`: lane q < 27 holds (first item, count) of neighbour q of a CENTRE block; the node's candidates along an axis are the
-// blocks centre + a and centre + a + 1 (a = -1 or 0), in whose tiles the node has coordinates t0 and t0 - 4.  All 64 lanes
-// must call (the neighbour table travels by ds_bpermute).
-template <int RB>
-__device__ __forceinline__ float4 gather_rel(const MpmPtrs& S, int2 mine, int ax, int ay, int az, int t0x, int t0y, int t0z, float4 acc) {
-    unsigned off[8];   // in float4 units from S.part_in: first item * kTN + staged position of this node in that block's tiles
-    int cb[8];         // items of the candidate block << 16 | this node's number in the tile (mask bit)
-    int maxc = 0;
-    // staged_index(tx, ty, tz) taken apart by axis: six small selects per axis and candidate side instead of ~30 per candidate
-    int ox[2], nx[2], rx[2], oy[2], ny[2], ry[2], oz[2], nz[2], rz[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        staged_axis(t0x - 4 * b, ox[b], nx[b], rx[b]);
-        staged_axis(t0y - 4 * b, oy[b], ny[b], ry[b]);
-        staged_axis(t0z - 4 * b, oz[b], nz[b], rz[b]);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int bx = c >> 2, by = (c >> 1) & 1, bz = c & 1;
-        const int dx = ax + bx, dy = ay + by, dz = az + bz;
-        const int src = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
-        const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
-        const int tx = t0x - 4 * bx, ty = t0y - 4 * by, tz = t0z - 4 * bz;  // this node inside that block's tile
-        const int si = ox[bx] * 64 + nx[bx] * (oy[by] * 8 + ny[by] * oz[bz]) + (rx[bx] * ny[by] + ry[by]) * nz[bz] + rz[bz];   // = staged_index(tx, ty, tz)
-        off[c] = (unsigned)first * kTN + (unsigned)si;
-        cb[c] = (n << 16) | ((tx * kTS + ty) * kTS + tz);
-        maxc = max(maxc, n);
-    }
-    // Eight rounds (items per candidate block) at a time.  Sparse tiles: first ALL mask words of these rounds (4 x 8 in flight,
-    // reduced to one bit each), then the tile loads that find something, RB rounds = 8 x RB loads in flight -- so a node covered
-    // by three items per block costs one round trip for the masks and ceil(3 / RB) for the tiles, not two per item.
-    // The order of the sum is (round, candidate) whatever RB: every instantiation returns the same bits.
-    // (Round 4 tried issuing the first round's tile loads TOGETHER with the mask loads and dropping unstored nodes afterwards --
-    // one dependent round trip fewer: 12.7 -> 15.5 us per launch at 1 M, the extra requests cost more than the trip saves;
-    // profiles/r4f_mpm_grid_speculative_tile_loads_rejected.txt.)
-    for (int r0 = 0; r0 < maxc; r0 += 8) {
-        unsigned long long live = ~0ull;     // bit r * 8 + c: the node is present in the tile of round r0 + r, candidate c
-        if (S.sparse_tiles) {                // (uniform)
-            live = 0ull;
-            for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += 4) {
-                const unsigned* mask32 = reinterpret_cast<const unsigned*>(S.mask_in);   // (little-endian halves of the 64-bit words)
-                unsigned w[4][8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int item = r0 + r1 + r;
-                        w[r][c] = (item < (cb[c] >> 16)) ? mask32[(size_t)((off[c] >> 9) + item) * 16 + ((cb[c] & 0xffff) >> 5)] : 0u;
-                    }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) live |= (unsigned long long)((w[r][c] >> (cb[c] & 31)) & 1u) << ((r1 + r) * 8 + c);
-            }
-        }
-        for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += RB) {
-            float4 q[RB][8];
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int item = r0 + r1 + r;
-                    const bool on = (item < (cb[c] >> 16)) && ((live >> ((r1 + r) * 8 + c)) & 1ull);
-                    q[r][c] = on ? S.part_in[off[c] + (unsigned)item * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
-        }
-    }
-    return acc;
-}
-// node (lx,ly,lz) of the block `mine` is centred on (the grid kernel's view)
-template <int RB>
-__device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
-    const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
-    return gather_rel<RB>(S, mine, ax, ay, az, lx - 4 * ax + 1, ly - 4 * ay + 1, lz - 4 * az + 1, acc);
-}
-
-// grid_normalization_and_gravity (mpm_utils.py:398-409), add_damping_via_grid (:583-588) and every BC for ONE node of block
-// (Bx,By,Bz), from its accumulated (m*v, m); returns grid_v_out
-__device__ __forceinline__ float4 finish_node(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, float4 g, int ix, int iy, int iz) {
-#pragma clang fp contract(off)
-    float v[3] = {0.0f, 0.0f, 0.0f};
-    if (g.w > 1e-15f) {
-        const float inv = 1.0f / g.w;
-        v[0] = g.x * inv + sp.dt * sp.g[0];
-        v[1] = g.y * inv + sp.dt * sp.g[1];
-        v[2] = g.z * inv + sp.dt * sp.g[2];
-    }
-    if (sp.do_damping) { v[0] *= sp.damping; v[1] *= sp.damping; v[2] *= sp.damping; }
-    for (int k = 0; k < bcs.n; ++k) apply_bc(bcs.bc[k], ix, iy, iz, S.ng, S.dx, sp.time, sp.dt, v);
-    return make_float4(v[0], v[1], v[2], 0.0f);
-}
-
-// (m*v, m) of ONE node summed by ONE lane, in gather_rel's order (round, candidate) -- no cross-lane traffic, so it can be
-// called from divergent code: the slow path of the one-launch substep, where grid_v_out of a node outside the workgroup's tile
-// does not exist in memory and is formed on the spot from the tiles that cover it.  Rare; rolled and out of line.
-__device__ __noinline__ float4 node_sum_lane(const float4* __restrict__ part_in, const unsigned long long* __restrict__ mask_in,
-                                             const int2* __restrict__ blk_items, int nbk, int sparse, int gx, int gy, int gz) {
-    const int mx = gx >> 2, my = gy >> 2, mz = gz >> 2, lx = gx & 3, ly = gy & 3, lz = gz & 3;
-    const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;
-    const unsigned* mask32 = reinterpret_cast<const unsigned*>(mask_in);
-    int maxc = 0;
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
-        const int bx = mx + ax + (c >> 2), by = my + ay + ((c >> 1) & 1), bz = mz + az + (c & 1);
-        if ((unsigned)bx < (unsigned)nbk && (unsigned)by < (unsigned)nbk && (unsigned)bz < (unsigned)nbk)
-            maxc = max(maxc, blk_items[(bx * nbk + by) * nbk + bz].y);
-    }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-    for (int r = 0; r < maxc; ++r)
-#pragma unroll 1
-        for (int c = 0; c < 8; ++c) {
-            const int dx = ax + (c >> 2), dy = ay + ((c >> 1) & 1), dz = az + (c & 1);
-            const int bx = mx + dx, by = my + dy, bz = mz + dz;
-            if (!((unsigned)bx < (unsigned)nbk && (unsigned)by < (unsigned)nbk && (unsigned)bz < (unsigned)nbk)) continue;
-            const int2 bi = blk_items[(bx * nbk + by) * nbk + bz];
-            if (r >= bi.y) continue;
-            const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;
-            const int bit = (tx * kTS + ty) * kTS + tz;
-            const size_t item = (size_t)(bi.x + r);
-            if (sparse && !((mask32[item * 16 + (bit >> 5)] >> (bit & 31)) & 1u)) continue;
-            const float4 q = part_in[item * kTN + staged_index(tx, ty, tz)];
-            acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
-        }
-    return acc;
-}
-
-// g2p of a particle whose stencil left its workgroup's tile, one-launch substep: the 27 grid_v_out values from the tiles
-// (+ the slow-path sums of generation fl_r), then the same sums as g2p_gather_global
-__device__ __forceinline__ void g2p_gather_from_tiles(const MpmPtrs& S, const StepParams& spg, const BCSet& bcs, const Stencil& st, float acc21[21]) {
-    float nv[3] = {0, 0, 0}, B[9], G[9];
-    for (int q = 0; q < 9; ++q) { B[q] = 0.0f; G[q] = 0.0f; }
-#pragma unroll 1
-    for (int t = 0; t < 27; ++t) {
-        const int i = t / 9, j = (t / 3) % 3, k = t % 3;
-        const int gx = st.base[0] + i, gy = st.base[1] + j, gz = st.base[2] + k;     // inside the grid (stencil_inside)
-        float4 m = node_sum_lane(S.part_in, S.mask_in, S.blk_items, S.nbk, S.sparse_tiles, gx, gy, gz);
-        if (S.blk_flags[((gx >> 2) * S.nbk + (gy >> 2)) * S.nbk + (gz >> 2)] & S.fl_r) {
-            const float4 e = S.gin_in[((size_t)gx * S.ng + gy) * S.ng + gz];
-            m.x += e.x; m.y += e.y; m.z += e.z; m.w += e.w;
-        }
-        const float4 u = finish_node(S, spg, bcs, m, gx, gy, gz);
-        const float g[3] = {u.x, u.y, u.z};
-        const float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
-        const float gw[3] = {st.dw[0][i] * st.w[1][j] * st.w[2][k], st.w[0][i] * st.dw[1][j] * st.w[2][k],
-                             st.w[0][i] * st.w[1][j] * st.dw[2][k]};
-        const float dp[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)k - st.fx[2]};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            nv[a] += w * g[a];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                B[3 * a + b] += w * g[a] * dp[b];
-                G[3 * a + b] += g[a] * gw[b];
-            }
-        }
-    }
-    for (int a = 0; a < 3; ++a) acc21[a] = nv[a];
-    for (int q = 0; q < 9; ++q) { acc21[3 + q] = B[q]; acc21[12 + q] = G[q]; }
 }
 
 // ------------------------------------------------------------------ fused block kernel
@@ -631,10 +381,9 @@ __device__ __forceinline__ void preload_particle(const MpmPtrs& S, int p, Preloa
     }
 }
 
-template <bool DO_G2P, bool DO_P2G, bool SCHED, bool CONSUME>
+template <bool DO_G2P, bool DO_P2G, bool SCHED>
 __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
-                                                int oz, const float4* tv, const Preload& L, ScatterIn& out,
-                                                const StepParams& spg, const BCSet& bcs) {
+                                                int oz, const float4* tv, const Preload& L, ScatterIn& out) {
     out.active = false;
     if (L.selection != 0) return;
     const int n = S.n;
@@ -667,8 +416,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         } else {
             atomicAdd(S.oob + 1, 1ull);
             float acc[21];
-            if (CONSUME) g2p_gather_from_tiles(S, spg, bcs, st, acc);
-            else g2p_gather_global(S.gout, S.ng, st, acc);
+            g2p_gather_global(S.gout, S.ng, st, acc);
 #pragma unroll
             for (int a = 0; a < 3; ++a) nv[a] = acc[a];
 #pragma unroll
@@ -871,26 +619,16 @@ __device__ unsigned long long g_mpm_trace[kMpmTraceItems * 8];
 constexpr int F_TRACE = 1;    // phase stamps + the ablation switches of StepParams.trace (timing studies only)
 constexpr int F_PACK32 = 2;   // packed 32-bit scatter (above)
 constexpr int F_WIDE = 8;     // no scheduling barriers: for scenes too small to fill the chip, where latency, not issue, binds
-constexpr int F_CONSUME = 16; // the one-launch substep (below)
 
 // OCC = waves per SIMD the register allocation is held to (launch_bounds).  Built without the SLP vectoriser (see
 // pixie_amd/build.py) the kernel needs 96 VGPRs -> 5 waves per SIMD with no spills (with it: 168 VGPRs, 3 waves, and
 // 20 % slower); 6 -> 80 VGPRs with ~20 spilled dwords (measured slower: 86 vs 81 us at 1 M particles).  Chosen at run
 // time (set_scalar "occupancy"), same arithmetic.
-//
-// F_CONSUME -- the ONE-LAUNCH substep: instead of copying grid_v_out of its 8^3 neighbourhood from memory, the workgroup forms it:
-// every staged node sums the tiles the PREVIOUS launch's P2G published for it (gather_rel: the grid kernel's gather, same order,
-// same bits), normalises, adds gravity, damping and every BC (finish_node with the grid update's own time and BC set, `spg` /
-// `bcs`).  The grid kernel and grid_v_out leave the step loop; tiles are double-buffered (read part_in, publish part).  A node is
-// covered by up to 8 tiles, so the staging reads grow eightfold -- out of L2 / MALL, where the tiles of the previous launch sit.
-template <bool DO_G2P, bool DO_P2G, int FL>
-__device__ __forceinline__ void mpm_block_body(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, const StepParams& spg, const BCSet& bcs) {
+template <bool DO_G2P, bool DO_P2G, int OCC, int FL>
+__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
     constexpr bool PACK = (FL & F_PACK32) != 0;
     constexpr bool TRACE = (FL & F_TRACE) != 0;
     constexpr bool SCHED = (FL & F_WIDE) == 0;
-    constexpr bool CONSUME = (FL & F_CONSUME) != 0;
-    constexpr int CRB = (FL & F_WIDE) ? 2 : 1;    // tile loads in flight per candidate block while consuming
-    static_assert(!CONSUME || (DO_G2P && DO_P2G), "the one-launch substep is the fused kernel");
     __shared__ float4 tv[kTN];    // grid velocities of the tile (G2P source)
     __shared__ unsigned long long ta[PACK ? 2 : 4][kTN];  // (m*v.xyz, m) of this work item as scaled integers (P2G target)
     __shared__ float s_red[2][kWG / 64];
@@ -904,10 +642,8 @@ __device__ __forceinline__ void mpm_block_body(const MpmPtrs& S, const StepParam
         const int per = (int)gridDim.x >> 3;
         if (item < (per << 3)) item = (item & 7) * per + (item >> 3);      // (the last n % 8 items keep their place)
     }
-    const int tid = threadIdx.x;
-    int2 mine = make_int2(0, 0);   // one-launch substep: lane q < 27 holds (first item, count) of neighbour block q of this item's block
-    if (CONSUME && (tid & 63) < 27) mine = S.item_nbr[(size_t)item * 32 + (tid & 63)];   // (a row per item: no dependent load)
     const int4 it = S.items[item];
+    const int tid = threadIdx.x;
     const int nthr = blockDim.x;   // = the work-item capacity of the current binning (256; 128 on request)
     const int bz = it.x % S.nbk, by = (it.x / S.nbk) % S.nbk, bx = it.x / (S.nbk * S.nbk);
     const int ox = bx * kBS - 1, oy = by * kBS - 1, oz = bz * kBS - 1;
@@ -916,54 +652,17 @@ __device__ __forceinline__ void mpm_block_body(const MpmPtrs& S, const StepParam
     Preload L;
     L.selection = 1;
     if (tid < it.z) preload_particle<DO_G2P, DO_P2G>(S, it.y + tid, L);   // in flight while the tile is staged
-    int nflags = 0;                // one-launch substep: blk_flags of neighbour block q (slow-path generations: rare)
-    if (CONSUME) {
-        const int q = tid & 63;
-        const int nx = bx + q / 9 - 1, ny = by + (q / 3) % 3 - 1, nz = bz + q % 3 - 1;
-        if (q < 27 && (unsigned)nx < (unsigned)S.nbk && (unsigned)ny < (unsigned)S.nbk && (unsigned)nz < (unsigned)S.nbk)
-            nflags = S.blk_flags[(nx * S.nbk + ny) * S.nbk + nz];
-    }
     for (int idx = tid; idx < kTN; idx += nthr) {
         if (DO_G2P) {
-            const int tz = idx & (kTS - 1), ty = (idx >> 3) & (kTS - 1), tx = idx >> 6;
-            const int gz = oz + tz, gy = oy + ty, gx = ox + tx;
-            const bool inside = (unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng;
+            const int gz = oz + (idx & (kTS - 1)), gy = oy + ((idx >> 3) & (kTS - 1)), gx = ox + (idx >> 6);
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (CONSUME) {
-                // tile coordinate t of this item = grid coordinate 4 B - 1 + t: own block B-1 (t = 0), B (1..4), B+1 (5..7); the tiles
-                // that cover it belong to blocks {B-1, B} (t < 4: coordinates t + 4 and t) or {B, B+1} (t >= 4: t and t - 4)
-                const int ax = tx < 4 ? -1 : 0, ay = ty < 4 ? -1 : 0, az = tz < 4 ? -1 : 0;
-                float4 m = gather_rel<CRB>(S, mine, ax, ay, az, tx - 4 * ax, ty - 4 * ay, tz - 4 * az, g);
-                if (__ballot((nflags & S.fl_r) != 0)) {        // slow-path sums of the previous P2G somewhere around: rare
-                    const int own = ((tx == 0) ? 0 : (tx <= 4 ? 1 : 2)) * 9 + ((ty == 0) ? 0 : (ty <= 4 ? 1 : 2)) * 3 + ((tz == 0) ? 0 : (tz <= 4 ? 1 : 2));
-                    const int f = __shfl(nflags, own);
-                    if (inside && (f & S.fl_r)) {
-                        const float4 e = S.gin_in[((size_t)gx * ng + gy) * ng + gz];
-                        m.x += e.x; m.y += e.y; m.z += e.z; m.w += e.w;
-                    }
-                }
-                if (inside) g = finish_node(S, spg, bcs, m, gx, gy, gz);
-            } else if (inside && !(TRACE && (sp.trace & 0x400))) {
+            if ((unsigned)gx < (unsigned)ng && (unsigned)gy < (unsigned)ng && (unsigned)gz < (unsigned)ng && !(TRACE && (sp.trace & 0x400)))
                 g = S.gout[((size_t)gx * ng + gy) * ng + gz];
-            }
             tv[idx] = g;
         }
         if (DO_P2G) {
             ta[0][idx] = 0ull; ta[1][idx] = 0ull;
             if (!PACK) { ta[2][idx] = 0ull; ta[3][idx] = 0ull; }
-        }
-    }
-    if (CONSUME && tid < 64) {
-        // generation z of gin (read by the launch before this one, written by the launch after it) is cleared here, where flagged:
-        // every active block is a neighbour of some work item; clearing twice is harmless, nobody else touches z in this launch
-        unsigned long long todo = __ballot((nflags & S.fl_z) != 0);
-        while (todo) {
-            const int q = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int nx = bx + q / 9 - 1, ny = by + (q / 3) % 3 - 1, nz = bz + q % 3 - 1;
-            const int ix = nx * kBS + (tid >> 4), iy = ny * kBS + ((tid >> 2) & 3), iz = nz * kBS + (tid & 3);
-            if (ix < ng && iy < ng && iz < ng) S.gin_old[((size_t)ix * ng + iy) * ng + iz] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid == 0) atomicAnd(&S.blk_flags[(nx * S.nbk + ny) * S.nbk + nz], ~S.fl_z);
         }
     }
     __syncthreads();
@@ -977,7 +676,7 @@ __device__ __forceinline__ void mpm_block_body(const MpmPtrs& S, const StepParam
     const int q = tid;
     ScatterIn in;
     in.active = false;
-    if (q < it.z) particle_phase1<DO_G2P, DO_P2G, SCHED, CONSUME>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in, spg, bcs);
+    if (q < it.z) particle_phase1<DO_G2P, DO_P2G, SCHED>(S, sp, pms, it.y + q, ox, oy, oz, tv, L, in);
     if (!DO_P2G) return;
     PX_MPM_STAMP(2);
 
@@ -1001,7 +700,7 @@ __device__ __forceinline__ void mpm_block_body(const MpmPtrs& S, const StepParam
                 for (int a = 0; a < 3; ++a) mvAT[a] = in.mv[a];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) { mvAT[3 + k] = in.A.m[k]; mvAT[12 + k] = in.T.m[k]; }
-                if (!p2g_scatter_global(S.gin, S.blk_flags, S.fl_w, S.nbk, ng, st, mvAT, in.mass)) atomicAdd(S.oob + 2, 1ull);
+                if (!p2g_scatter_global(S.gin, S.blk_flags, S.nbk, ng, st, mvAT, in.mass)) atomicAdd(S.oob + 2, 1ull);
                 in.active = false;
             }
         }
@@ -1110,19 +809,6 @@ __device__ __forceinline__ void mpm_block_body(const MpmPtrs& S, const StepParam
 #endif
 }
 
-template <bool DO_G2P, bool DO_P2G, int OCC, int FL>
-__global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepParams sp, PModSet pms) {
-    static_assert((FL & F_CONSUME) == 0, "the one-launch substep has its own entry point");
-    BCSet none;
-    none.n = 0;
-    mpm_block_body<DO_G2P, DO_P2G, FL>(S, sp, pms, sp, none);
-}
-// the one-launch substep: grid update of substep t (spg, bcs) + G2P of t + modifiers, stress, P2G of t + 1 (sp)
-template <int OCC, int FL>
-__global__ __launch_bounds__(kWG, OCC) void mpm_substep_kernel(MpmPtrs S, StepParams sp, PModSet pms, StepParams spg, BCSet bcs) {
-    mpm_block_body<true, true, FL | F_CONSUME>(S, sp, pms, spg, bcs);
-}
-
 // ------------------------------------------------------------------ re-binning (counting sort by block)
 __device__ __forceinline__ int block_of(const MpmPtrs& S, int p) {
     int b[3];
@@ -1167,36 +853,88 @@ __global__ __launch_bounds__(256) void bin_count_kernel(MpmPtrs S, int* __restri
     if (valid) { keys[p] = key; rank[p] = my_rank; }
 }
 
-// exclusive scan of the block counts + the work list (<= kWG particles per item), one workgroup
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets,
-                                                        int4* __restrict__ items, int2* __restrict__ blk_items,
-                                                        int* __restrict__ n_items, int nblocks, int cap) {
-    __shared__ int s_cnt[1024], s_itm[1024];
-    const int tid = threadIdx.x;
-    const int per = (nblocks + 1023) / 1024;
-    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
-    int csum = 0, isum = 0, iother = 0;
-    const int other = (cap == kWG) ? kWG / 2 : kWG;     // how many items the other capacity would make (auto item_cap, see rebin())
-    for (int b = b0; b < b1; ++b) { const int c = counts[b]; csum += c; isum += (c + cap - 1) / cap; iother += (c + other - 1) / other; }
-    if (iother) atomicAdd(&n_items[3], iother);
-    s_cnt[tid] = csum; s_itm[tid] = isum;
+// Exclusive scan of the block counts + the work list (<= cap particles per item), in three launches over chunks of 1024 blocks:
+// chunk totals -> scan of the chunk totals (one workgroup) -> scan inside each chunk + the writes.  (Until round 5 ONE 1024-thread
+// workgroup walked all blocks: 58 us for the 27 000 blocks of a 120^3 grid, 280 us for the 125 000 of the reference's sand configuration
+// at n_grid 200 -- 7 % of that scene's run at a re-binning every ~33 substeps; profiles/r5last_stats_sand.csv.)
+constexpr int kScanChunk = 1024;
+struct ScanTriple { int cnt, itm, other; };   // particles, work items at `cap`, work items at the other capacity (auto item_cap, see rebin())
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+// exclusive prefix of v over the 1024-thread workgroup; *total = the workgroup's sum
+__device__ __forceinline__ int wg_excl_scan_1024(int v, int* s_wave /* [16] */, int* total) {
+    const int incl = wave_incl_scan(v);
+    const int w = threadIdx.x >> 6;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int a = 0, b = 0;
-        if (tid >= off) { a = s_cnt[tid - off]; b = s_itm[tid - off]; }
-        __syncthreads();
-        s_cnt[tid] += a; s_itm[tid] += b;
-        __syncthreads();
+    if ((threadIdx.x & 63) == 63) s_wave[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int t = s_wave[k]; if (k < w) base += t; tot += t; }
+    *total = tot;
+    return base + incl - v;
+}
+__device__ __forceinline__ ScanTriple scan_triple_of(int c, int cap) {
+    const int other = (cap == kWG) ? kWG / 2 : kWG;
+    return ScanTriple{c, (c + cap - 1) / cap, (c + other - 1) / other};
+}
+__global__ __launch_bounds__(kScanChunk) void bin_scan_partial_kernel(const int* __restrict__ counts, ScanTriple* __restrict__ chunk, int nblocks, int cap) {
+    __shared__ int s_w[3][16];
+    const int b = blockIdx.x * kScanChunk + threadIdx.x;
+    const ScanTriple t = scan_triple_of(b < nblocks ? counts[b] : 0, cap);
+    int v[3] = {t.cnt, t.itm, t.other};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        if ((threadIdx.x & 63) == 0) s_w[k][threadIdx.x >> 6] = v[k];
     }
-    int c = s_cnt[tid] - csum, i = s_itm[tid] - isum;  // exclusive prefixes
-    for (int b = b0; b < b1; ++b) {
-        const int cnt = counts[b];
-        offsets[b] = c;
-        blk_items[b] = make_int2(i, (cnt + cap - 1) / cap);
-        for (int j = 0; j < cnt; j += cap) items[i++] = make_int4(b, c + j, min(cap, cnt - j), 0);
-        c += cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ScanTriple r{0, 0, 0};
+        for (int w = 0; w < 16; ++w) { r.cnt += s_w[0][w]; r.itm += s_w[1][w]; r.other += s_w[2][w]; }
+        chunk[blockIdx.x] = r;
     }
-    if (tid == 1023) *n_items = s_itm[1023];
+}
+// chunk totals -> exclusive prefixes (in place); n_items[0] = work items, n_items[3] = what the other capacity would make.  One workgroup.
+__global__ __launch_bounds__(1024) void bin_scan_chunks_kernel(ScanTriple* __restrict__ chunk, int nchunks, int* __restrict__ n_items) {
+    __shared__ int s_w[16];
+    const int per = (nchunks + 1023) / 1024;
+    const int c0 = min((int)threadIdx.x * per, nchunks), c1 = min(c0 + per, nchunks);
+    ScanTriple mine{0, 0, 0};
+    for (int c = c0; c < c1; ++c) { mine.cnt += chunk[c].cnt; mine.itm += chunk[c].itm; mine.other += chunk[c].other; }
+    int tc, ti, to;
+    int pc = wg_excl_scan_1024(mine.cnt, s_w, &tc);
+    int pi = wg_excl_scan_1024(mine.itm, s_w, &ti);
+    int po = wg_excl_scan_1024(mine.other, s_w, &to);
+    for (int c = c0; c < c1; ++c) {
+        const ScanTriple t = chunk[c];
+        chunk[c] = ScanTriple{pc, pi, po};
+        pc += t.cnt; pi += t.itm; po += t.other;
+    }
+    if (threadIdx.x == 0) { n_items[0] = ti; n_items[3] = to; }
+}
+__global__ __launch_bounds__(kScanChunk) void bin_scan_write_kernel(const int* __restrict__ counts, const ScanTriple* __restrict__ chunk,
+                                                                    int* __restrict__ offsets, int4* __restrict__ items,
+                                                                    int2* __restrict__ blk_items, int nblocks, int cap) {
+    __shared__ int s_w[16];
+    const int b = blockIdx.x * kScanChunk + threadIdx.x;
+    const int cnt = b < nblocks ? counts[b] : 0;
+    const int nit = (cnt + cap - 1) / cap;
+    const ScanTriple base = chunk[blockIdx.x];
+    int dummy;
+    const int c = base.cnt + wg_excl_scan_1024(cnt, s_w, &dummy);
+    int i = base.itm + wg_excl_scan_1024(nit, s_w, &dummy);
+    if (b >= nblocks) return;
+    offsets[b] = c;
+    blk_items[b] = make_int2(i, nit);
+    for (int j = 0; j < cnt; j += cap) items[i++] = make_int4(b, c + j, min(cap, cnt - j), 0);
 }
 
 __global__ __launch_bounds__(256) void bin_order_kernel(const int* __restrict__ keys, const int* __restrict__ rank,
@@ -1323,22 +1061,6 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
     }
 }
 
-// One 256-byte row per work item: blk_items of the 27 neighbours of its block (lane q < 27 of the one-launch block kernel loads
-// entry q; entries 27..31 pad the row).  Indexed by the ITEM, so that the load does not wait for items[item].
-__global__ __launch_bounds__(256) void bin_item_nbr_kernel(const int4* __restrict__ items, const int2* __restrict__ blk_items,
-                                                           int2* __restrict__ item_nbr, int n_items, int nbk) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int item = t >> 5, q = t & 31;
-    if (item >= n_items) return;
-    int2 v = make_int2(0, 0);
-    if (q < 27) {
-        const int b = items[item].x;
-        const int x = b / (nbk * nbk) + q / 9 - 1, y = (b / nbk) % nbk + (q / 3) % 3 - 1, z = b % nbk + q % 3 - 1;
-        if ((unsigned)x < (unsigned)nbk && (unsigned)y < (unsigned)nbk && (unsigned)z < (unsigned)nbk) v = blk_items[(x * nbk + y) * nbk + z];
-    }
-    item_nbr[(size_t)item * 32 + q] = v;
-}
-
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
 __global__ __launch_bounds__(256) void bin_permute_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
                                                           const int* __restrict__ order, int n, int rows_per_y) {
@@ -1357,7 +1079,151 @@ __global__ void iota_kernel(int* dst, int n) {
     if (i < n) dst[i] = i;
 }
 
-// ------------------------------------------------------------------ grid kernel (node helpers: above the block kernel)
+// ------------------------------------------------------------------ grid kernel
+// grid_normalization_and_gravity (mpm_utils.py:398-409), add_damping_via_grid (:583-588) and the
+// BC `collide` closures (mpm_solver_warp.py:785-840 surface, :874-897 cuboid, :917-974 bounding box)
+// in one sweep; also re-zeroes (m*v, m) so the next P2G starts from a clean grid (zero_grid :295-300).
+// (No FMA contraction in apply_bc / finish_node: whether `float(k) * dx - point` is fused decides on which side of a collider plane a
+// node plane lies (tests: knife-edge scene), and hipcc's choice depends on the code around it.  Every operation rounded, as in the
+// float32 oracle -- the same bits in whatever kernel these are inlined into.)
+__device__ __forceinline__ void apply_bc(const BCDev& b, int ix, int iy, int iz, int ng, float dx, float time,
+                                         float dt, float v[3]) {
+#pragma clang fp contract(off)
+    if (b.type == PIXIE_BC_SURFACE) {
+        if (time >= b.start && time < b.end) {
+            const float ox = (float)ix * dx - b.point[0], oy = (float)iy * dx - b.point[1], oz = (float)iz * dx - b.point[2];
+            const float dp = ox * b.normal[0] + oy * b.normal[1] + oz * b.normal[2];
+            if (dp < 0.0f) {
+                if (b.surface_type == 11) {
+                    if ((float)iz * dx < 0.4f || (float)iz * dx > 0.53f) {
+                        v[0] = v[1] = v[2] = 0.0f;
+                    } else {
+                        v[0] = v[0] * 0.3f; v[1] = 0.0f; v[2] = v[2] * 0.3f;
+                    }
+                } else {
+                    // sticky, and -- as in the reference (:821-840) -- slip/friction too: the projected
+                    // velocity is computed there but the store is zero.
+                    v[0] = v[1] = v[2] = 0.0f;
+                }
+            }
+        }
+    } else if (b.type == PIXIE_BC_CUBOID) {
+        if (time >= b.start && time < b.end) {
+            const float ox = (float)ix * dx - b.point[0], oy = (float)iy * dx - b.point[1], oz = (float)iz * dx - b.point[2];
+            if (fabsf(ox) < b.size[0] && fabsf(oy) < b.size[1] && fabsf(oz) < b.size[2]) {
+                v[0] = b.velocity[0]; v[1] = b.velocity[1]; v[2] = b.velocity[2];
+            }
+        } else if (b.reset == 1) {
+            if (time < b.end + 15.0f * dt) v[0] = v[1] = v[2] = 0.0f;
+        }
+    } else {
+        const int padding = 3;
+        if (time >= b.start && time < b.end) {
+            if (ix < padding && v[0] < 0.0f) v[0] = 0.0f;
+            if (ix >= ng - padding && v[0] > 0.0f) v[0] = 0.0f;
+            if (iy < padding && v[1] < 0.0f) v[1] = 0.0f;
+            if (iy >= ng - padding && v[1] > 0.0f) v[1] = 0.0f;
+            if (iz < padding && v[2] < 0.0f) v[2] = 0.0f;
+            if (iz >= ng - padding && v[2] > 0.0f) v[2] = 0.0f;
+        }
+    }
+}
+
+// (m*v, m) of node (gx,gy,gz) = what slow-path particles added to gin + the tiles of the work items that cover the node.
+// A node with g = 4m + r along an axis lies in the tiles of blocks {m-1, m} (r < 3) or {m, m+1} (r = 3) on that axis:
+// 8 candidate blocks per node, all among the 27 neighbours of the node's own block.  The wave first fetches the 27
+// (first item, count) pairs with one load (lane i < 27), then every lane walks its 8 candidates in rounds so that the
+// 8 tile loads of a round are in flight together.  The order of the sum is fixed; every staged value is read once.
+// lane i < 27 fetches (first item, count) of neighbour block i of block (Bx,By,Bz); other lanes get (0,0)
+__device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By, int Bz) {
+    const int lane = threadIdx.x & 63;
+    int2 mine = make_int2(0, 0);
+    if (lane < 27) {
+        const int bx = Bx + lane / 9 - 1, by = By + (lane / 3) % 3 - 1, bz = Bz + lane % 3 - 1;
+        if ((unsigned)bx < (unsigned)S.nbk && (unsigned)by < (unsigned)S.nbk && (unsigned)bz < (unsigned)S.nbk)
+            mine = S.blk_items[(bx * S.nbk + by) * S.nbk + bz];
+    }
+    return mine;
+}
+// RB = items per candidate block fetched in one go (8 x RB tile loads in flight)
+template <int RB>
+__device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
+    const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
+    unsigned off[8];   // in float4 units from S.part: first item * kTN + staged position of this node in that block's tiles
+    int cb[8];         // items of the candidate block << 16 | this node's number in the tile (mask bit)
+    int maxc = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int dx = ax + (c >> 2), dy = ay + ((c >> 1) & 1), dz = az + (c & 1);
+        const int src = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
+        const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
+        const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;  // this node inside that block's tile
+        off[c] = (unsigned)first * kTN + (unsigned)staged_index(tx, ty, tz);
+        cb[c] = (n << 16) | ((tx * kTS + ty) * kTS + tz);
+        maxc = max(maxc, n);
+    }
+    // Eight rounds (items per candidate block) at a time.  Sparse tiles: first ALL mask words of these rounds (4 x 8 in flight,
+    // reduced to one bit each), then the tile loads that find something, RB rounds = 8 x RB loads in flight -- so a node covered
+    // by three items per block costs one round trip for the masks and ceil(3 / RB) for the tiles, not two per item.
+    // The order of the sum is (round, candidate) whatever RB: every instantiation returns the same bits.
+    // (Round 4 tried issuing the first round's tile loads TOGETHER with the mask loads and dropping unstored nodes afterwards --
+    // one dependent round trip fewer: 12.7 -> 15.5 us per launch at 1 M, the extra requests cost more than the trip saves;
+    // profiles/r4f_mpm_grid_speculative_tile_loads_rejected.txt.)
+    for (int r0 = 0; r0 < maxc; r0 += 8) {
+        unsigned long long live = ~0ull;     // bit r * 8 + c: the node is present in the tile of round r0 + r, candidate c
+        if (S.sparse_tiles) {                // (uniform)
+            live = 0ull;
+            for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += 4) {
+                const unsigned* mask32 = reinterpret_cast<const unsigned*>(S.tile_mask);   // (little-endian halves of the 64-bit words)
+                unsigned w[4][8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int item = r0 + r1 + r;
+                        w[r][c] = (item < (cb[c] >> 16)) ? mask32[(size_t)((off[c] >> 9) + item) * 16 + ((cb[c] & 0xffff) >> 5)] : 0u;
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) live |= (unsigned long long)((w[r][c] >> (cb[c] & 31)) & 1u) << ((r1 + r) * 8 + c);
+            }
+        }
+        for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += RB) {
+            float4 q[RB][8];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int item = r0 + r1 + r;
+                    const bool on = (item < (cb[c] >> 16)) && ((live >> ((r1 + r) * 8 + c)) & 1ull);
+                    q[r][c] = on ? S.part[off[c] + (unsigned)item * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
+        }
+    }
+    return acc;
+}
+
+// grid_normalization_and_gravity (mpm_utils.py:398-409), add_damping_via_grid (:583-588) and every BC for ONE node of block
+// (Bx,By,Bz), from its accumulated (m*v, m); returns grid_v_out
+__device__ __forceinline__ float4 finish_node(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, float4 g, int ix, int iy, int iz) {
+#pragma clang fp contract(off)
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    if (g.w > 1e-15f) {
+        const float inv = 1.0f / g.w;
+        v[0] = g.x * inv + sp.dt * sp.g[0];
+        v[1] = g.y * inv + sp.dt * sp.g[1];
+        v[2] = g.z * inv + sp.dt * sp.g[2];
+    }
+    if (sp.do_damping) { v[0] *= sp.damping; v[1] *= sp.damping; v[2] *= sp.damping; }
+    for (int k = 0; k < bcs.n; ++k) apply_bc(bcs.bc[k], ix, iy, iz, S.ng, S.dx, sp.time, sp.dt, v);
+    return make_float4(v[0], v[1], v[2], 0.0f);
+}
+
 // One WAVE updates the 4x4x4 nodes of active block `slot`: gather the staged tiles (+ what slow-path particles added to gin),
 // normalise, gravity, damping, BCs -> dst.
 template <int RB>
@@ -1369,22 +1235,20 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
     int2 mine;
     mine.x = __shfl(row.x, (lane + 1) & 63); mine.y = __shfl(row.y, (lane + 1) & 63);
     const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
-    // bit 0: active (set at re-binning); bits 1..3: slow-path particles added fp32 atomics into that generation of gin here
+    // bit 0: active (set at re-binning); bit 1: slow-path particles added fp32 atomics into gin here
     const int flag = S.blk_flags[blk];
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
     const int ix = Bx * kBS + lx, iy = By * kBS + ly, iz = Bz * kBS + lz;
     const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = gather_node<RB>(S, mine, lx, ly, lz, make_float4(0.f, 0.f, 0.f, 0.f));   // does not wait for the flag
-    if (flag & (S.fl_r | S.fl_z)) {
-        if (inside && (flag & S.fl_r)) {
-            const float4 q = S.gin_in[idx];
+    if (flag & 2) {
+        if (inside) {
+            const float4 q = S.gin[idx];
             g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
-            S.gin_in[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        // (a one-launch substep before this one read generation z and left it for its successor to clear: that is us)
-        if (inside && (flag & S.fl_z)) S.gin_old[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (lane == 0) S.blk_flags[blk] = flag & ~(S.fl_r | S.fl_z);
+        if (lane == 0) S.blk_flags[blk] = flag & 1;
     }
     if (!inside) return;
     dst[idx] = finish_node(S, sp, bcs, g, ix, iy, iz);
@@ -1400,6 +1264,9 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
 // scene with ~1.2 items per block and 9000 active blocks (1 M in 120^3) wants the registers back: RB = 1 = 101 VGPRs = 4 waves
 // per SIMD, 14.9 -> 12.5 us per launch together with the sparse tiles.  (Holding the allocation to 80 / 64 VGPRs for 6 / 8 waves
 // spills 22 / 39 dwords: 20.4 / 25.5 us.  profiles/r3s_mpm_grid_kernel_occupancy.txt)
+// (Four active blocks per 256-thread workgroup instead of one wave per workgroup: measured equal at 3 700 active blocks in round 3 and again
+// at the 15 700 of the reference's sand configuration in round 6 -- 21.99 vs 21.0 us, 102.0 vs 101.8 us per substep; the launch is not
+// dispatch-bound.  profiles/r6c_sand_timing.txt)
 template <int RB>
 __global__ __launch_bounds__(64) void mpm_grid_block_kernel(MpmPtrs S, StepParams sp, BCSet bcs, int mode) {
     if (mode == 0) {
@@ -1423,7 +1290,7 @@ __global__ __launch_bounds__(64) void grid_export_pending_kernel(MpmPtrs S, floa
     const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inside) g = S.gin_in[idx];
+    if (inside) g = S.gin[idx];
     g = gather_node<4>(S, neighbour_items(S, Bx, By, Bz), lx, ly, lz, g);
     if (!inside) return;
     if (what == 0) out[idx] = g.w;
@@ -1439,7 +1306,7 @@ __global__ __launch_bounds__(256) void mpm_grid_kernel(MpmPtrs S, StepParams sp,
     const int ix = (int)(idx / ((long)S.ng * S.ng));
     float v[3] = {0.0f, 0.0f, 0.0f};
     if (normalise) {
-        const float4 g = S.gin_in[idx];
+        const float4 g = S.gin[idx];
         if (g.w > 1e-15f) {
             const float inv = 1.0f / g.w;
             v[0] = g.x * inv + sp.dt * sp.g[0];
@@ -1447,7 +1314,7 @@ __global__ __launch_bounds__(256) void mpm_grid_kernel(MpmPtrs S, StepParams sp,
             v[2] = g.z * inv + sp.dt * sp.g[2];
         }
         if (sp.do_damping) { v[0] *= sp.damping; v[1] *= sp.damping; v[2] *= sp.damping; }
-        if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) S.gin_in[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) S.gin[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     } else {
         const float4 o = S.gout[idx];
         v[0] = o.x; v[1] = o.y; v[2] = o.z;
@@ -1704,15 +1571,10 @@ struct pixie_mpm {
     int comp_x = 0;                          // set_scalar "compensated_x"
     int xcd_order = 1;                       // set_scalar "xcd_order" (on: 63.5 -> 61.9 us per substep at 1 M, 18.0 -> 17.5 at 100 k, same bits; profiles/r5g_xcd_order.txt)
     bool pmods_were_active = false;
-    float4* part2[2] = {nullptr, nullptr};   // staged tiles of a P2G, [max_items][kTN]; two copies: a one-launch substep reads one and publishes the other
-    unsigned long long* mask2[2] = {nullptr, nullptr}; // [max_items][8] occupancy bits of the staged tiles
-    int tile_cur = 0;                        // the copy that holds the latest P2G's tiles
-    float4* gin3[3] = {nullptr, nullptr, nullptr};     // three generations of the slow-path sums (see MpmPtrs)
-    int gen = 0;                             // the generation the latest P2G wrote
-    int2* item_nbr = nullptr;                // [max_items][32] (see bin_item_nbr_kernel)
-    int one_launch = -1;                     // set_scalar "one_launch": -1 auto, 0 two launches per substep, 1 one launch wherever possible
-    long n_one_launch = 0;                   // substeps that ran as one launch (get_scalar "one_launch_substeps")
+    float4* part = nullptr;                  // staged tiles of the last P2G, [max_items][kTN]
+    unsigned long long* tile_mask = nullptr; // [max_items][8] occupancy bits of the staged tiles
     int grid_rb = 0;                         // grid kernel: tile loads in flight per candidate block (0 = by scene size; 1, 2, 4)
+    ScanTriple* scan_chunks = nullptr;       // [ceil(nblocks / 1024)] re-binning scan scratch
     int sparse = -1;                         // sparse tile publishing: -1 auto (on when the work list exceeds two items per CU), 0, 1
     bool pending_p2g = false;                // staged tiles not yet consumed by the grid kernel
     int* blk_flags = nullptr;
@@ -1756,25 +1618,6 @@ int dev_alloc(pixie_mpm* h, T** ptr, size_t count, bool grid_sized = false) {
 // fewer dependent loads the better (whole tiles, RB = 4: 18.7 vs 20.9 us per substep).
 bool grid_kernel_crowded(const pixie_mpm* h) { return h->n_active > 8 * h->n_cus; }
 
-// Tiles and slow-path sums as the TWO-launch substep sees them: its P2G publishes into the copy / generation its grid kernel
-// then reads (and clears).  A one-launch substep takes a private view (substep_view) and advances tile_cur / gen.
-void bind_buffers(pixie_mpm* h) {
-    MpmPtrs& S = h->S;
-    S.part = h->part2[h->tile_cur]; S.tile_mask = h->mask2[h->tile_cur];
-    S.part_in = S.part; S.mask_in = S.tile_mask;
-    S.gin = h->gin3[h->gen]; S.gin_in = S.gin; S.gin_old = h->gin3[(h->gen + 2) % 3];
-    S.fl_w = S.fl_r = 2 << h->gen; S.fl_z = 2 << ((h->gen + 2) % 3);
-}
-// grid update of the pending P2G + G2P + the next P2G in one launch: read (tile_cur, gen), publish (tile_cur ^ 1, gen + 1), clear gen - 1
-MpmPtrs substep_view(const pixie_mpm* h) {
-    MpmPtrs S = h->S;
-    const int w = h->tile_cur ^ 1, gw = (h->gen + 1) % 3, gz = (h->gen + 2) % 3;
-    S.part = h->part2[w]; S.tile_mask = h->mask2[w];
-    S.gin = h->gin3[gw]; S.gin_old = h->gin3[gz];
-    S.fl_w = 2 << gw; S.fl_z = 2 << gz;
-    return S;
-}
-
 // point the row pointers of h->S at the current copy of the word array
 void bind_rows(pixie_mpm* h) {
     MpmPtrs& S = h->S;
@@ -1785,9 +1628,19 @@ void bind_rows(pixie_mpm* h) {
     S.vol = f + R_VOL * n; S.mass = f + R_MASS * n; S.density = f + R_DENSITY * n; S.E = f + R_E * n; S.nu = f + R_NU * n;
     S.mu = f + R_MU * n; S.lam = f + R_LAM * n; S.bulk = f + R_BULK * n; S.ys = f + R_YS * n;
     S.material = i + R_MATERIAL * n; S.selection = i + R_SELECTION * n; S.perm = i + R_PERM * n; S.xref = f + R_XREF * n; S.xlo = f + R_XLO * n;
-    S.items = h->items; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
-    S.item_nbr = h->item_nbr;
-    bind_buffers(h);
+    S.items = h->items; S.part = h->part; S.tile_mask = h->tile_mask; S.blk_items = h->blk_items; S.blk_flags = h->blk_flags; S.active_list = h->active_list; S.nbr_table = h->nbr_table;
+}
+
+// counts -> offsets, work list, per-block item ranges (three scan launches), active blocks + their neighbour rows
+void build_work_list(pixie_mpm* h, hipStream_t st) {
+    const int nchunks = cdiv(h->nblocks, kScanChunk);
+    hipLaunchKernelGGL(bin_scan_partial_kernel, dim3(nchunks), dim3(kScanChunk), 0, st, h->counts, h->scan_chunks, h->nblocks, h->item_cap);
+    hipLaunchKernelGGL(bin_scan_chunks_kernel, dim3(1), dim3(1024), 0, st, h->scan_chunks, nchunks, h->d_n_items);
+    hipLaunchKernelGGL(bin_scan_write_kernel, dim3(nchunks), dim3(kScanChunk), 0, st, h->counts, h->scan_chunks, h->offsets, h->items, h->blk_items,
+                       h->nblocks, h->item_cap);
+    (void)hipMemsetAsync(h->d_n_items + 1, 0, sizeof(int), st);
+    hipLaunchKernelGGL(bin_mark_active_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->counts, h->blk_flags, h->active_list,
+                       h->d_n_items + 1, h->S.nbk, h->blk_items, h->nbr_table);  // (rewrites every flag: no slow-path writes are pending here)
 }
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
@@ -1801,17 +1654,14 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     // Automatic: 128-thread items in scenes so sparse that few blocks hold more than 128 particles -- there a 256-thread
     // workgroup runs two waves without a particle (the reference's sand configuration at 1 M: 120 -> 108 us per substep) -- and
     // 256 everywhere else (1 M in 120^3: 62.5 vs 70.9 us; 100 k in 50^3: 17.5 vs 21.8; profiles/r5e_item_cap_sparse_scenes.txt).
-    // Decided from the counts of the PREVIOUS re-binning (both item counts come back with it): see the end of this function.
+    // Decided from the block histogram of THIS re-binning (both item counts come back with it; if the choice flips, only the work
+    // list is built again -- three small launches): see below.
     h->item_cap = h->item_cap_user > 0 ? h->item_cap_user : (h->auto_half_items ? kWG / 2 : kWG);
-    PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 3, 0, sizeof(int), st));
     PX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->nblocks * sizeof(int), st));
     PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 2, 0, sizeof(int), st));
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, S, h->keys, h->rank, h->counts,
                        reinterpret_cast<unsigned*>(h->d_n_items + 2));
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, h->counts, h->offsets, h->items, h->blk_items, h->d_n_items, h->nblocks, h->item_cap);
-    PX_CHECK_HIP(hipMemsetAsync(h->d_n_items + 1, 0, sizeof(int), st));
-    hipLaunchKernelGGL(bin_mark_active_kernel, dim3(cdiv(h->nblocks, 256)), dim3(256), 0, st, h->counts, h->blk_flags, h->active_list,
-                       h->d_n_items + 1, S.nbk, h->blk_items, h->nbr_table);  // (rewrites every flag: no slow-path writes are pending here)
+    build_work_list(h, st);
     hipLaunchKernelGGL(bin_order_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->keys, h->rank, h->offsets, h->order, n);
     // keys/rank are free again: reuse them as the local kernel's scratch
     hipLaunchKernelGGL(bin_local_order_kernel, dim3((unsigned)h->nblocks), dim3(256), 0, st, S, h->counts, h->offsets, h->order, h->keys,
@@ -1839,14 +1689,24 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     }
     h->n_items = h->h_n_items[0];
     h->n_active = h->h_n_items[1];
-    if (h->n_items > 0)
-        hipLaunchKernelGGL(bin_item_nbr_kernel, dim3(cdiv((long)h->n_items * 32, 256)), dim3(256), 0, st, h->items, h->blk_items, h->item_nbr, h->n_items, S.nbk);
-    {   // half-size work items from the next re-binning on iff they would be nearly as few as full-size ones: <= 15 % more.
+    if (h->item_cap == kWG || h->item_cap == kWG / 2) {
+        // Half-size work items iff they would be nearly as few as full-size ones: enter at <= 15 % more, leave above 25 % (a scene
+        // near the threshold does not flip at every re-binning; the per-item fixed-point scale depends on the item size).
         // (Break-even measured near +20 %: 1 M jelly in 200^3, +22 % items, 89.6 vs 90.6 us; the sand configuration, +2 ... 8 % over its
         // run, 120 -> 108 us; dense scenes, +64 ... 74 % items, lose 13 %.  profiles/r5e_item_cap_sparse_scenes.txt)
         const long other = h->h_n_items[3];
         const long n256 = (h->item_cap == kWG) ? h->n_items : other, n128 = (h->item_cap == kWG) ? other : h->n_items;
-        if (h->item_cap == kWG || h->item_cap == kWG / 2) h->auto_half_items = n128 * 100 <= n256 * 115;
+        if (!h->auto_half_items) h->auto_half_items = n128 * 100 <= n256 * 115;
+        else h->auto_half_items = n128 * 100 <= n256 * 125;
+        const int want = h->auto_half_items ? kWG / 2 : kWG;
+        if (h->item_cap_user == 0 && want != h->item_cap) {   // in force from THIS binning: rebuild the work list for the other capacity
+            h->item_cap = want;
+            build_work_list(h, st);
+            PX_CHECK_HIP(hipMemcpyAsync(h->h_n_items, h->d_n_items, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            PX_CHECK_HIP(hipStreamSynchronize(st));
+            h->n_items = h->h_n_items[0];
+            h->n_active = h->h_n_items[1];
+        }
     }
     if (measure_mass) {
         float lo, hi;
@@ -1862,7 +1722,9 @@ int rebin(pixie_mpm* h, hipStream_t st) {
     // predicts the next one -- aim at 0.4 cells, never more than four times the last interval (a re-binning of 1 M
     // particles costs ~0.4 ms = 4 substeps: with doubling, the ramp 4, 8, ..., 256 of a quiet scene spent six of them in
     // the first 252 substeps), and halve when > 0.1 % of the particles were on the slow path.  (The host enqueues substeps
-    // far ahead of the device, so this is the only feedback.)
+    // far ahead of the device, so this is the only feedback.)  The 0.4 is not slack to be spent: aiming at 0.55 / 0.7 cells buys the
+    // reference's sand configuration 1 / 2 % (9 -> 6 re-binnings in 400 substeps) and costs a 100 k scene in motion 34 % / 183 % -- an
+    // accelerating scene overshoots the prediction and lands on the slow path (profiles/r6d_drift_target.txt).
     if (h->resort_auto) {
         unsigned long long slow_total;
         memcpy(&slow_total, h->h_n_items + 4, sizeof slow_total);
@@ -1943,12 +1805,12 @@ BCSet make_bcset(const pixie_mpm* h, size_t first) {
 
 // host `modify` of moving cuboids (mpm_solver_warp.py:899-905) after the grid update of the substep at h->time:
 // python-float maths, stored as f32
-void advance_bcs_at(pixie_mpm* h, double dt, double time) {
+void advance_bcs(pixie_mpm* h, double dt) {
     for (size_t k = 0; k < h->bcs.size(); ++k) {
         pixie_bc_desc& b = h->bcs[k];
         if (b.type != PIXIE_BC_CUBOID) continue;
         const double t0 = (double)(float)b.start_time, t1 = (double)(float)b.end_time;
-        if (time >= t0 && time < t1) {
+        if (h->time >= t0 && h->time < t1) {
             for (int d = 0; d < 3; ++d) {
                 const float np = (float)((double)h->bcs_dev[k].point[d] + dt * (double)h->bcs_dev[k].velocity[d]);
                 h->bcs_dev[k].point[d] = np;
@@ -1957,8 +1819,6 @@ void advance_bcs_at(pixie_mpm* h, double dt, double time) {
         }
     }
 }
-
-void advance_bcs(pixie_mpm* h, double dt) { advance_bcs_at(h, dt, h->time); }
 
 template <bool G, bool P, int OCC, int FL>
 void launch_block(const pixie_mpm* h, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms) {
@@ -1971,26 +1831,13 @@ void launch_block_p(const pixie_mpm* h, bool pack, dim3 grid, hipStream_t st, co
     else launch_block<G, P, OCC, BASE>(h, grid, st, sp, pms);
 }
 
-template <int OCC, int FL>
-void launch_substep(const pixie_mpm* h, dim3 grid, hipStream_t st, const StepParams& sp, const PModSet& pms, const StepParams& spg, const BCSet& bcs) {
-    hipLaunchKernelGGL((mpm_substep_kernel<OCC, FL>), grid, dim3(h->item_cap), 0, st, substep_view(h), sp, pms, spg, bcs);
-}
-
-// Latency-optimised variant (no scheduling barriers, 130 VGPRs = three waves per SIMD = three 256-thread work items per CU at
-// once): up to that many the whole work list is resident in one round and a launch lasts one work item's latency.
-bool wide_variant(const pixie_mpm* h) { return h->wide == 1 || (h->wide < 0 && h->n_items <= 3 * h->n_cus); }
-
-// the fused G2P + P2G launch in the variant the scene calls for; with (spg, bcs) the one-launch substep: the grid update of the
-// pending P2G happens in the staging loop of the same kernel (F_CONSUME)
-void launch_fused_block(const pixie_mpm* h, hipStream_t st, const StepParams& sp, const PModSet& pms, const StepParams* spg = nullptr, const BCSet* bcs = nullptr) {
+// the fused G2P + P2G launch in the variant the scene calls for
+void launch_fused_block(const pixie_mpm* h, hipStream_t st, const StepParams& sp, const PModSet& pms) {
     const dim3 grid((unsigned)std::max(h->n_items, 1));
     const bool pack = h->scatter_bits == 32;
-    const bool wide = wide_variant(h);
-    if (spg) {
-        if (wide) { if (pack) launch_substep<2, F_WIDE | F_PACK32>(h, grid, st, sp, pms, *spg, *bcs); else launch_substep<2, F_WIDE>(h, grid, st, sp, pms, *spg, *bcs); }
-        else { if (pack) launch_substep<5, F_PACK32>(h, grid, st, sp, pms, *spg, *bcs); else launch_substep<5, 0>(h, grid, st, sp, pms, *spg, *bcs); }
-        return;
-    }
+    // Latency-optimised variant (no scheduling barriers, 130 VGPRs = three waves per SIMD = three 256-thread work items per CU at
+    // once): up to that many the whole work list is resident in one round and a launch lasts one work item's latency.
+    const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 3 * h->n_cus);
 #ifdef PIXIE_DIAG
     if (h->trace) { launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms); return; }
 #endif
@@ -2012,13 +1859,9 @@ std::vector<PModDev> active_pmods(const pixie_mpm* h, float time) {
     return ordered;
 }
 
-// a re-binning is due before the next block kernel
-bool rebin_due(const pixie_mpm* h) { return h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval); }
-
-// (spg, bcs): the one-launch substep -- the caller has checked substep_can_be_one_launch()
-int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st, const StepParams* spg = nullptr, const BCSet* bcs = nullptr) {
+int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st) {
     // (never while staged tiles are waiting for the grid kernel: the work list they are indexed by must not change)
-    if (!h->pending_p2g && rebin_due(h))
+    if (!h->pending_p2g && (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval)))
         if (rebin(h, st)) return 1;
     if (g2p) ++h->steps_since_sort;
     const int blocks = cdiv(h->S.n, 256);
@@ -2041,13 +1884,7 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
         PX_CHECK_HIP(hipEventCreate(&e0)); PX_CHECK_HIP(hipEventCreate(&e1));
         PX_CHECK_HIP(hipEventRecord(e0, st));
     }
-    if (spg) {          // grid update + G2P + P2G in one launch
-        launch_fused_block(h, st, sp, pms, spg, bcs);
-        h->tile_cur ^= 1;
-        h->gen = (h->gen + 1) % 3;
-        bind_buffers(h);
-        ++h->n_one_launch;
-    } else if (g2p && p2g && fused_mods) {
+    if (g2p && p2g && fused_mods) {
         launch_fused_block(h, st, sp, pms);
     } else {
         if (g2p) {
@@ -2069,17 +1906,6 @@ int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipS
     PX_CHECK_HIP(hipGetLastError());
     if (p2g) h->pending_p2g = true;
     return 0;
-}
-
-// One launch per substep (the block kernel forms grid_v_out of its neighbourhood from the pending tiles) when: asked for or -- auto --
-// the scene is in the latency-bound regime (the whole work list resident at once), where the grid kernel and its boundary are 40 %
-// of a substep; a P2G is pending; no re-binning is due (the tiles are indexed by the current work list); BCs and modifiers fit one
-// launch; no per-launch timing is being taken.  `next_time`: the time of the P2G the launch would carry.
-bool substep_can_be_one_launch(const pixie_mpm* h, double next_time) {
-    const bool want = h->one_launch == 1 || (h->one_launch < 0 && wide_variant(h));
-    if (!want || !h->pending_p2g || h->n_items == 0 || rebin_due(h) || h->profile || h->trace) return false;
-    if (h->bcs_dev.size() > (size_t)kMaxBCPerLaunch) return false;
-    return active_pmods(h, (float)next_time).size() <= (size_t)kMaxPModFused;
 }
 
 void launch_grid_blocks(const pixie_mpm* h, hipStream_t st, const StepParams& sp, const BCSet& set, int mode, int n_wg) {
@@ -2146,21 +1972,22 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     PX_REQUIRE(max_items * (size_t)kTN < ((size_t)1 << 32), "pixie_mpm: %zu work items exceed the 32-bit tile offsets of the grid kernel (2^23 items)", max_items);
     std::vector<void*> old;
     old.swap(h->grid_allocs);
-    float4 *gin[3] = {nullptr, nullptr, nullptr}, *gout = nullptr, *part[2] = {nullptr, nullptr};
-    unsigned long long* tile_mask[2] = {nullptr, nullptr};
+    float4 *gin = nullptr, *gout = nullptr, *part = nullptr;
+    unsigned long long* tile_mask = nullptr;
     int *counts = nullptr, *offsets = nullptr, *active_list = nullptr, *blk_flags = nullptr;
     int4* items = nullptr;
-    int2 *nbr_table = nullptr, *blk_items = nullptr, *item_nbr = nullptr;
+    int2 *nbr_table = nullptr, *blk_items = nullptr;
     int rc = 0;
-    for (int g = 0; g < 3; ++g) rc |= dev_alloc(h, &gin[g], G, true);
-    rc |= dev_alloc(h, &gout, G, true);
+    rc |= dev_alloc(h, &gin, G, true); rc |= dev_alloc(h, &gout, G, true);
     rc |= dev_alloc(h, &counts, (size_t)nblocks, true); rc |= dev_alloc(h, &offsets, (size_t)nblocks, true);
     rc |= dev_alloc(h, &items, max_items, true);
     rc |= dev_alloc(h, &active_list, (size_t)nblocks, true);
     rc |= dev_alloc(h, &nbr_table, (size_t)nblocks * 28, true);
     rc |= dev_alloc(h, &blk_items, (size_t)nblocks, true); rc |= dev_alloc(h, &blk_flags, (size_t)nblocks, true);
-    for (int c = 0; c < 2; ++c) { rc |= dev_alloc(h, &part[c], max_items * kTN, true); rc |= dev_alloc(h, &tile_mask[c], max_items * 8, true); }
-    rc |= dev_alloc(h, &item_nbr, max_items * 32, true);
+    ScanTriple* scan_chunks = nullptr;
+    rc |= dev_alloc(h, &scan_chunks, (size_t)cdiv(nblocks, kScanChunk), true);
+    rc |= dev_alloc(h, &part, max_items * kTN, true);
+    rc |= dev_alloc(h, &tile_mask, max_items * 8, true);
     if (rc) {   // keep the old grid
         for (void* p : h->grid_allocs) (void)hipFree(p);
         h->grid_allocs.swap(old);
@@ -2173,13 +2000,12 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     S.inv_dx = (float)((double)n_grid / grid_lim);
     S.nbk = nbk;
     h->nblocks = nblocks;
-    S.gout = gout;
-    for (int g = 0; g < 3; ++g) h->gin3[g] = gin[g];
-    for (int c = 0; c < 2; ++c) { h->part2[c] = part[c]; h->mask2[c] = tile_mask[c]; }
-    h->tile_cur = 0; h->gen = 0;
+    S.gin = gin; S.gout = gout;
     h->counts = counts; h->offsets = offsets; h->items = items; h->active_list = active_list; h->nbr_table = nbr_table;
-    h->blk_items = blk_items; h->blk_flags = blk_flags; h->item_nbr = item_nbr;
+    h->blk_items = blk_items; h->blk_flags = blk_flags; h->part = part; h->tile_mask = tile_mask;
+    h->scan_chunks = scan_chunks;
     h->n_items = 0; h->n_active = 0;
+    h->auto_half_items = false;
     h->needs_sort = true; h->xref_valid = false;
     h->pending_p2g = false; h->dirty_grid = false; h->gout_sparse = false;
     if (h->resort_auto) h->resort_interval = 4;
@@ -2283,6 +2109,7 @@ int pixie_mpm_set_field(pixie_mpm* h, const char* name, const void* d_src, int64
     if (nm == "material") h->needs_sort = true;     // the order inside a block goes by material class
     if (nm == "x") {   // positions replaced: binning stale, frozen particles get another chance
         h->needs_sort = true; h->xref_valid = false; h->resort_interval = h->resort_auto ? 4 : h->resort_interval;
+        h->auto_half_items = false;   // a new scene decides its work-item capacity afresh, like a new handle
         hipLaunchKernelGGL(unfreeze_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, h->S.selection, n);
         h->mass_range_dirty = true;   // re-admitted particles count towards the mass contrast again
         PX_CHECK_HIP(hipMemsetAsync(h->S.xlo, 0, (size_t)3 * n * sizeof(float), st));   // new positions carry no remainder
@@ -2304,7 +2131,7 @@ int pixie_mpm_get_field(pixie_mpm* h, const char* name, void* d_dst, int64_t cou
     if (nm == "grid_m" || nm == "grid_v_in" || nm == "grid_v_out") {
         const int k = (nm == "grid_m") ? 1 : 3;
         PX_REQUIRE(count == (int64_t)G * k, "get_field(%s): expected %lld scalars, got %lld", name, (long long)G * k, (long long)count);
-        const float4* src = (nm == "grid_v_out") ? h->S.gout : h->S.gin_in;
+        const float4* src = (nm == "grid_v_out") ? h->S.gout : h->S.gin;
         if (nm == "grid_v_out" && h->gout_sparse) {  // bring the skipped (massless, far from any particle) blocks up to date
             BCSet set{};
             set.n = (int)h->last_grid_bcs.size();
@@ -2373,7 +2200,9 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
 #ifdef PIXIE_DIAG
     else if (k == "profile") h->profile = value != 0.0;
 #else
-    else if (k == "profile" || k == "trace") return set_error("pixie_mpm_set_scalar(%s): diagnostic switch, only in the PIXIE_DIAG build (libpixie_hip_diag.so)", key);
+    else if (k == "profile" || k == "trace") {   // switching them OFF is a no-op everywhere (callers written against the round-4 library do that)
+        if (value != 0.0) return set_error("pixie_mpm_set_scalar(%s): diagnostic switch, only in the PIXIE_DIAG build (libpixie_hip_diag.so)", key);
+    }
 #endif
     else if (k == "scatter_bits") {
         PX_REQUIRE(value == 64 || value == 32 || value == 0, "scatter_bits must be 0 (auto: by mass contrast), 64 (exact) or 32 (packed pairs)");
@@ -2386,7 +2215,6 @@ int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value) {
 #ifdef PIXIE_DIAG
     else if (k == "trace") h->trace = (int)value;
 #endif
-    else if (k == "one_launch") { PX_REQUIRE(value == -1 || value == 0 || value == 1, "one_launch must be -1 (auto), 0 or 1"); h->one_launch = (int)value; }
     else if (k == "compensated_x") h->comp_x = value != 0.0 ? 1 : 0;
     else if (k == "xcd_order") h->xcd_order = value != 0.0 ? 1 : 0;
     else if (k == "occupancy") { PX_REQUIRE(value == 5 || value == 6, "occupancy must be 5 or 6 waves per SIMD"); h->occupancy = (int)value; }
@@ -2413,8 +2241,6 @@ int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value) {
     else if (k == "mass_contrast") *value = h->mass_contrast;
     else if (k == "n_active_blocks") *value = h->n_active;
     else if (k == "n_rebins") *value = (double)h->n_sorts;
-    else if (k == "one_launch") *value = h->one_launch;
-    else if (k == "one_launch_substeps") *value = (double)h->n_one_launch;     // substeps that ran as ONE launch so far
     else if (k == "lost_particles_seen") *value = (double)h->lost_seen;   // as of the last re-binning; does not synchronise
     else if (k == "dropped_particles") {  // slow-path particles that had left every active block; synchronises the device
         unsigned long long v = 0;
@@ -2512,19 +2338,9 @@ int pixie_mpm_step(pixie_mpm* h, double dt, int n_substeps, void* stream) {
     // substep 0: modifiers + stress + P2G at time t0
     if (launch_particle(h, false, true, make_params(h, dt, h->time), st)) return 1;
     for (int i = 0; i < n_substeps; ++i) {
-        const bool last = (i == n_substeps - 1);
-        if (!last && substep_can_be_one_launch(h, h->time + dt)) {
-            // grid update of substep i (at the old time, with the BCs as they stand) + G2P of i + modifiers / stress / P2G of i + 1
-            const double t_grid = h->time;
-            const StepParams spg = make_params(h, dt, t_grid);
-            const BCSet set = make_bcset(h, 0);
-            h->time = h->time + dt;  // mpm_solver_warp.py:637
-            if (launch_particle(h, true, true, make_params(h, dt, h->time), st, &spg, &set)) return 1;
-            advance_bcs_at(h, dt, t_grid);
-            continue;
-        }
         if (launch_grid(h, make_params(h, dt, h->time), dt, st)) return 1;
         h->time = h->time + dt;  // mpm_solver_warp.py:637
+        const bool last = (i == n_substeps - 1);
         // G2P of substep i fused with modifiers/stress/P2G of substep i+1 (evaluated at the new time)
         if (launch_particle(h, true, !last, make_params(h, dt, h->time), st)) return 1;
     }

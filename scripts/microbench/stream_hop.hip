@@ -75,6 +75,30 @@ int main() {
         }
         CK(hipDeviceSynchronize());
         const double ser = us(t0) / N;
+        // (6) the overlap pattern as a captured graph (fork / join through events while capturing: edges become graph dependencies)
+        double gpat = -1.0;
+        {
+            const int M = 50;
+            hipGraph_t graph; hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(s1, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < M; ++i) {
+                hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s1, a, b, cyc);
+                CK(hipEventRecord(ev[2 * i], s1)); CK(hipStreamWaitEvent(s2, ev[2 * i], 0));
+                hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s2, c, a, (long)500);
+                hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s1, b, a, cyc);
+                CK(hipEventRecord(ev[2 * i + 1], s1)); CK(hipStreamWaitEvent(s2, ev[2 * i + 1], 0));
+                hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s2, d, b, (long)200);
+                CK(hipEventRecord(ev[2 * i], s2)); CK(hipStreamWaitEvent(s1, ev[2 * i], 0));
+            }
+            CK(hipStreamEndCapture(s1, &graph)); CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(exec, s1)); CK(hipStreamSynchronize(s1));
+            t0 = clk::now();
+            for (int k = 0; k < 10; ++k) CK(hipGraphLaunch(exec, s1));
+            CK(hipStreamSynchronize(s1));
+            gpat = us(t0) / (10.0 * M);
+            hipGraphExecDestroy(exec); hipGraphDestroy(graph);
+        }
+        printf("the same pattern as ONE captured graph of 50 substeps (edges = graph dependencies): %.2f us per substep\n", gpat);
         printf("pair of near-empty kernels: one stream %.2f us | every edge across two streams %.2f us (= %.2f us per cross-stream hop more) | two independent chains %.2f us per pair of pairs\n",
                one, cross, (cross - one) / 2, indep);
         printf("overlap pattern (2 x 25 us block halves, 5 us grid half hidden, 2 us seam exposed): %.2f us per substep against %.2f us serial (25 + 25 + 7): %+.2f us\n", pat, ser, pat - ser);

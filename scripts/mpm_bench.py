@@ -44,7 +44,7 @@ def main():
         s._set_scalar("occupancy", int(os.environ["PIXIE_MPM_OCC"]))
     if os.environ.get("PIXIE_MPM_ITEM_CAP"):
         s._set_scalar("item_cap", int(os.environ["PIXIE_MPM_ITEM_CAP"]))
-    for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb"), ("PIXIE_MPM_XCD", "xcd_order"), ("PIXIE_MPM_ONE", "one_launch")):
+    for env, key in (("PIXIE_MPM_BITS", "scatter_bits"), ("PIXIE_MPM_WIDE", "wide"), ("PIXIE_MPM_SPARSE", "sparse_tiles"), ("PIXIE_MPM_GRID_RB", "grid_rb"), ("PIXIE_MPM_XCD", "xcd_order")):
         if os.environ.get(env):
             s._set_scalar(key, int(os.environ[env]))
     if os.environ.get("PIXIE_MPM_V0"):     # a scene in motion: random particle velocities of this rms per component (strains of a few %)
@@ -67,7 +67,7 @@ def main():
         s.set_profile(False)
     alg = 212.0 * n + 44.0 * ng ** 3
     print(f"n={n} ng={ng} resort={resort} {scenario} lib={'diag' if diag else 'product'} occ={os.environ.get('PIXIE_MPM_OCC', '5')} dbg={os.environ.get('PIXIE_MPM_TRACE', '0')} cap={os.environ.get('PIXIE_MPM_ITEM_CAP', 'auto')}->{int(s._get_scalar('item_cap'))} "
-          f"one={os.environ.get('PIXIE_MPM_ONE', 'auto')}({int(s._get_scalar('one_launch_substeps'))}) bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} v0={os.environ.get('PIXIE_MPM_V0', '0')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
+          f"bits={os.environ.get('PIXIE_MPM_BITS', 'dflt')} v0={os.environ.get('PIXIE_MPM_V0', '0')} wide={os.environ.get('PIXIE_MPM_WIDE', 'auto')}: {1e6 * dt / steps:.2f} us/substep  {n * steps / dt:.3e} particle-steps/s  "
           f"alg {alg * steps / dt / 1e9:.1f} GB/s ({alg * steps / dt / 8e12 * 100:.2f}% of 8TB/s) | fused kernel {1e3 * p_ms:.2f} us "
           f"({212.0 * n / (max(p_ms, 1e-9) * 1e-3) / 1e9:.1f} GB/s) grid kernel {1e3 * g_ms:.2f} us | items {int(s._get_scalar('n_work_items'))} "
           f"active blocks {int(s._get_scalar('n_active_blocks'))} rebins {int(s._get_scalar('n_rebins'))} (timed region: {rebins_timed}) slow {int(s._get_scalar('slow_path_particles'))} oob {s.out_of_bounds} "

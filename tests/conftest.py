@@ -41,21 +41,3 @@ def hip_device():
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu but no HIP device is visible")
     return torch.device("cuda:0")
-
-
-@pytest.fixture(autouse=True)
-def _force_one_launch(monkeypatch):
-    """PIXIE_TEST_ONE_LAUNCH=0|1 runs the whole suite with the MPM solver's "one_launch" switch forced (default: the library's
-    automatic choice) -- every parity test then holds that substep form to the oracle."""
-    v = os.environ.get("PIXIE_TEST_ONE_LAUNCH", "")
-    if v == "":
-        yield
-        return
-    from pixie_amd import mpm_solver
-    orig = mpm_solver.MPM_Simulator_WARP.initialize
-
-    def initialize(self, *a, **k):
-        orig(self, *a, **k)
-        self._set_scalar("one_launch", int(v))
-    monkeypatch.setattr(mpm_solver.MPM_Simulator_WARP, "initialize", initialize)
-    yield

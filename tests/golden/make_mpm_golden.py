@@ -17,6 +17,12 @@ Per checkpoint (substeps 20, 100, 500, 1000) the fixture holds, from the float64
 and, from the float32 run of the same oracle, `drift_*` / `drift_agg_*`: its distance from the float64 run over all
 particles (x, the displacement, v, C, F_trial; the norm ratios, total momentum and centre of mass) -- the rounding-error floor that any float32 implementation (the reference's Warp kernels
 included) is entitled to, which the GPU test uses to scale its tolerances.
+
+Round 6 ("say what the config-3 drift is"): the float32 run's own trajectory is stored too -- `x32_`, `v32_`, `C32_`,
+`F_trial32_` of the same every-16th particles -- so that the GPU test can measure product-vs-float32-oracle directly instead of inferring it
+from two similar distances to the float64 run; and `order_{cp}` = the distance (displacement, v, C, F_trial; all particles) between that
+float32 run and a SECOND float32 run of the same algorithm that differs only in the order of the P2G sums (the OpenMP build scatters tile by
+tile, 8 colours, instead of particle by particle): how far two legitimate float32 evaluations of the reference's algorithm are from each other.
 """
 import os
 import sys
@@ -44,7 +50,7 @@ def make(scene, precision):
 
 def main(out_name="mpm_config3.npz", checkpoints=CHECKPOINTS):
     sc = mpm_ball_scene(N, seed=SEED)
-    runs = {p: make(sc, p) for p in ("f64", "f32")}
+    runs = {p: make(sc, p) for p in ("f64", "f32", "f32_omp")}
     snaps = {p: {} for p in runs}
 
     def work(p):
@@ -70,9 +76,12 @@ def main(out_name="mpm_config3.npz", checkpoints=CHECKPOINTS):
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
     for cp in checkpoints:
-        s64, s32 = snaps["f64"][cp], snaps["f32"][cp]
+        s64, s32, s32b = snaps["f64"][cp], snaps["f32"][cp], snaps["f32_omp"][cp]
         for f in ("x", "v", "F_trial", "C"):
             res[f"{f}_{cp}"] = s64[f][::STRIDE]
+            res[f"{f}32_{cp}"] = s32[f][::STRIDE].astype(np.float32)
+        res[f"order_{cp}"] = np.array([rel(s32b["x"] - x0, s32["x"] - x0), rel(s32b["v"], s32["v"]), rel(s32b["C"], s32["C"]),
+                                       rel(s32b["F_trial"], s32["F_trial"])])
         res[f"norms_{cp}"] = np.array([np.linalg.norm(s64["x"] - x0), np.linalg.norm(s64["v"]), np.linalg.norm(s64["C"]),
                                        np.linalg.norm(s64["F_trial"] - eye)])
         res[f"momentum_{cp}"] = (mass[:, None] * s64["v"]).sum(0)
@@ -86,7 +95,8 @@ def main(out_name="mpm_config3.npz", checkpoints=CHECKPOINTS):
         res[f"drift_agg_{cp}"] = np.concatenate([np.abs(n32 / res[f"norms_{cp}"] - 1.0),
                                                  [np.linalg.norm((mass[:, None] * s32["v"]).sum(0) - res[f"momentum_{cp}"]) / (mass.sum() * v_rms),
                                                   np.abs((mass[:, None] * s32["x"]).sum(0) / mass.sum() - res[f"com_{cp}"]).max()]])
-        print(cp, "norms", res[f"norms_{cp}"], "drift (x, disp, v, C, F)", res[f"drift_{cp}"], "aggregates", res[f"drift_agg_{cp}"], flush=True)
+        print(cp, "norms", res[f"norms_{cp}"], "drift (x, disp, v, C, F)", res[f"drift_{cp}"], "aggregates", res[f"drift_agg_{cp}"],
+              "two float32 summation orders apart (disp, v, C, F)", res[f"order_{cp}"], flush=True)
     np.savez_compressed(os.path.join(HERE, out_name), **res)
     print("wrote", out_name, f"{time.time() - t0:.0f} s")
 
