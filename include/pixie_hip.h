@@ -66,8 +66,12 @@ int pixie_mpm_fill_field(pixie_mpm* h, const char* name, double value, void* str
  * No reference counterpart: "compensated_x" (0, the default = the reference's float32 `x += dt v`, mpm_utils.py:447; 1 = the
  * rounding error of that sum is carried in three more words per particle and fed into the next increment, so the stored x is the
  * float32 rounding of the accumulated position: displacement error vs float64 4-8x smaller in quiet scenes, +5 % per substep),
- * "scatter_bits" (0 = by the particle-mass contrast, 32, 64), "occupancy", "item_cap", "wide", "sparse_tiles", "grid_rb",
- * "resort_interval" (kernel variants, see csrc/mpm.hip). */
+ * "scatter_bits" (0 = by the particle-mass contrast, 32, 64), "occupancy", "item_cap" (0 = automatic: decided at every re-binning from
+ * that binning's block histogram, with hysteresis; get_scalar "item_cap" returns the capacity in force), "wide", "sparse_tiles",
+ * "grid_rb", "resort_interval", "xcd_order" (1, the default: the block kernel's workgroups take the block-ordered work list in
+ * contiguous runs per XCD -- same bits, 2.6 % faster; 0: round-robin) (kernel variants, see csrc/mpm.hip).
+ * "profile" / "trace": diagnostic switches of the PIXIE_DIAG build (libpixie_hip_diag.so); the product library accepts 0 (a no-op)
+ * and refuses any other value. */
 int pixie_mpm_set_scalar(pixie_mpm* h, const char* key, double value);
 int pixie_mpm_get_scalar(pixie_mpm* h, const char* key, double* value);
 

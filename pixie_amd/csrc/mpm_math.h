@@ -14,8 +14,10 @@
 
 #if defined(__HIPCC__)
 #define PX_HD __host__ __device__ __forceinline__
+#define PX_RARE static __host__ __device__ __forceinline__   // rare paths: out of line, so that their registers stay out of the hot kernels' budget
 #else
 #define PX_HD inline
+#define PX_RARE inline
 #endif
 
 #ifndef PX_SVD_NEWTON_SCHULZ
@@ -247,6 +249,47 @@ PX_HD void svd3(const Mat3& F, Mat3& U, float sig[3], Mat3& V, int* sweeps_out =
     sig[2] = u2[0] * B(0, 2) + u2[1] * B(1, 2) + u2[2] * B(2, 2);
 }
 
+// Crushed elements (one stretch below half the largest): forming F F^T squares the condition number, so the Jacobi iteration on it
+// resolves the eigen-frame only to ~1e-7 lam_max ABSOLUTE -- two small axes keep a mutual rotation of 1e-7 lam_max / (lam_p - lam_q)
+// (sigma = (1, 1e-2, 2e-2): 3e-4 rad), and sqrt(lam_d) an error of 1e-7 lam_max / sig_d.  The columns a_d = F^T u_d
+// (= sig_d v_d) come from F itself and are accurate relative to |F|: one sweep of one-sided (Hestenes) rotations that make them
+// orthogonal, applied to U alike, finishes the frame; sig_d = |a_d|, a sum of squares, accurate relative to sig_d itself.
+// Rare and out of line: keeps its registers out of the block kernel's budget.
+struct FrameSig { Mat3 U; float sig[3]; };
+// (Arguments and result BY VALUE and every index static after unrolling: an out-of-line function that takes references or indexes its
+// arrays at run time puts its operands in scratch, and the scratch frame of the deepest call path is allocated for EVERY wave of the
+// kernel -- 500 instead of 292 bytes per lane cost every MPM scene 20 %, jelly included; profiles/r6e_scratch_regression.txt.)
+PX_RARE FrameSig refine_crushed_frame(Mat3 F, Mat3 U) {
+    float a[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[d][c] = F(0, c) * U(0, d) + F(1, c) * U(1, d) + F(2, c) * U(2, d);
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+        const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+        const float al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
+        const float be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
+        const float ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
+        const bool rot = ga * ga > 1.0e-14f * al * be;              // else: orthogonal to float32 resolution already (or NaN / a null column)
+        const float zeta = (be - al) / (2.0f * (rot ? ga : 1.0f));
+        const float t = ((zeta >= 0.0f) ? 1.0f : -1.0f) / (fabsf(zeta) + px_sqrt(1.0f + zeta * zeta));
+        const float c = rot ? px_rsqrt(1.0f + t * t) : 1.0f, sn = rot ? c * t : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float ap = a[p][k], aq = a[q][k];
+            a[p][k] = c * ap - sn * aq; a[q][k] = sn * ap + c * aq;
+            const float up = U(k, p), uq = U(k, q);
+            U(k, p) = c * up - sn * uq; U(k, q) = sn * up + c * uq;
+        }
+    }
+    FrameSig r;
+    r.U = U;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) r.sig[d] = px_sqrt(a[d][0] * a[d][0] + a[d][1] * a[d][1] + a[d][2] * a[d][2]);
+    return r;
+}
+
 // Left principal frame of F, the only part of the SVD the constitutive laws need:  F F^T = U diag(sig^2) U^T  by the same
 // cyclic Jacobi iteration run on b = F F^T (accumulating U), sig_d = sqrt(lam_d), U a proper rotation, axes UNSORTED.
 // For det F < 0 the sign goes to the singular value of smallest magnitude -- Warp's convention (see svd3), the one thing of
@@ -283,18 +326,15 @@ PX_HD void left_stretch(const Mat3& F, float det_F, Mat3& U, float sig[3], int* 
     sig[0] = px_sqrt(fmaxf(l0, 0.0f)); sig[1] = px_sqrt(fmaxf(l1, 0.0f)); sig[2] = px_sqrt(fmaxf(l2, 0.0f));
     // An eigenvalue of F F^T carries an absolute error of ~1e-7 lam_max, i.e. sig_d one of 1e-7 lam_max / sig_d: fine while the
     // stretches are within a factor 2 of each other (every stable simulation), not for a crushed element.  There (rare,
-    // the lane's own test) sig_d = |F^T u_d| instead: a sum of squares, accurate relative to sig_d itself.
+    // the lane's own test) the small axes are finished on F itself -- see refine_crushed_frame.
     if (fminf(fminf(l0, l1), l2) < 0.25f * fmaxf(fmaxf(l0, l1), l2)) {
-        for (int d = 0; d < 3; ++d) {
-            const float a0 = F(0, 0) * U(0, d) + F(1, 0) * U(1, d) + F(2, 0) * U(2, d);
-            const float a1 = F(0, 1) * U(0, d) + F(1, 1) * U(1, d) + F(2, 1) * U(2, d);
-            const float a2 = F(0, 2) * U(0, d) + F(1, 2) * U(1, d) + F(2, 2) * U(2, d);
-            sig[d] = px_sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-        }
+        const FrameSig r = refine_crushed_frame(F, U);
+        U = r.U;
+        sig[0] = r.sig[0]; sig[1] = r.sig[1]; sig[2] = r.sig[2];
     }
     if (det_F < 0.0f) {
-        if (l0 <= l1 && l0 <= l2) sig[0] = -sig[0];
-        else if (l1 <= l2) sig[1] = -sig[1];
+        if (sig[0] <= sig[1] && sig[0] <= sig[2]) sig[0] = -sig[0];
+        else if (sig[1] <= sig[2]) sig[1] = -sig[1];
         else sig[2] = -sig[2];
     }
 }
@@ -627,6 +667,60 @@ PX_HD Mat3 kirchhoff_stress(int material, const Mat3& F, float mu, float lam, fl
     return tau;
 }
 
+// A yielded F_trial with a singular value at float32's zero (|sigma_d| <= 1e-6 sigma_max, zero itself included): sigma'_d / sigma_d
+// is infinite and the correction form F_trial + U diag(sigma'/sigma - 1) U^T F_trial turns the particle into NaN, which P2G spreads to
+// its neighbours.  The reference re-assembles F = U diag(sigma') V^T, which stays finite -- the point of its max(sigma, 0.01)
+// clamp -- so the same is done here: v_d = F_trial^T u_d / sigma_d on the regular axes, the null axes completed to a right-handed
+// orthonormal frame (one null axis: the cross product of the other two, unique; more: any completion, as arbitrary as an SVD's own).
+PX_HD void cross3(const float p[3], const float q[3], float w[3]) {
+    w[0] = p[1] * q[2] - p[2] * q[1]; w[1] = p[2] * q[0] - p[0] * q[2]; w[2] = p[0] * q[1] - p[1] * q[0];
+    const float rn = px_rsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    w[0] *= rn; w[1] *= rn; w[2] *= rn;
+}
+struct Vec3s { float a, b, c; };
+PX_RARE Mat3 rebuild_rank_deficient(Mat3 Ft, Mat3 U, Vec3s so_, Vec3s sn_, float amax) {
+    const float so[3] = {so_.a, so_.b, so_.c}, sn[3] = {sn_.a, sn_.b, sn_.c};
+    float v[3][3];
+    bool reg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        reg[d] = fabsf(so[d]) > 1.0e-6f * amax;
+        const float inv = reg[d] ? 1.0f / so[d] : 0.0f;
+        float n2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[d][c] = (Ft(0, c) * U(0, d) + Ft(1, c) * U(1, d) + Ft(2, c) * U(2, d)) * inv; n2 += v[d][c] * v[d][c]; }
+        const float rn = reg[d] ? px_rsqrt(n2) : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[d][c] *= rn;
+    }
+    const int n_reg = (reg[0] ? 1 : 0) + (reg[1] ? 1 : 0) + (reg[2] ? 1 : 0);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {           // ONE regular axis a: a unit vector orthogonal to it (cross with the coordinate axis it is least aligned with)
+        const int b = (a + 1) % 3;
+        if (n_reg == 1 && reg[a]) {
+            const float ax = fabsf(v[a][0]), ay = fabsf(v[a][1]), az = fabsf(v[a][2]);
+            const bool ex = ax <= ay && ax <= az, ey = !ex && ay <= az;
+            const float e[3] = {ex ? 1.0f : 0.0f, ey ? 1.0f : 0.0f, (!ex && !ey) ? 1.0f : 0.0f};
+            cross3(v[a], e, v[b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {           // (now two axes are known) the last one: v_d = v_{d+1} x v_{d+2}, right-handed with the other two
+        const int d = (a + 2) % 3, b = (a + 1) % 3;      // d, a, b cyclic
+        if (n_reg == 1 ? reg[a] : (n_reg == 2 && !reg[d])) cross3(v[a], v[b], v[d]);
+    }
+    Mat3 F;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // F_trial = 0 (or not finite): V = U
+            const float v0 = n_reg ? v[0][c] : U(c, 0), v1 = n_reg ? v[1][c] : U(c, 1), v2 = n_reg ? v[2][c] : U(c, 2);
+            F(r, c) = sn[0] * U(r, 0) * v0 + sn[1] * U(r, 1) * v1 + sn[2] * U(r, 2) * v2;
+        }
+    return F;
+}
+
 // compute_stress_from_F_trial, mpm_utils.py:467-526: F = returnMap(F_trial); tau = stress(F).
 // mu/lam/ys are the particle's mutable model entries (snow damage and hardening write them).
 PX_HD void return_map_and_stress(int material, const Mat3& Ft, float& mu, float& lam, float bulk, float& ys,
@@ -638,8 +732,14 @@ PX_HD void return_map_and_stress(int material, const Mat3& Ft, float& mu, float&
         const float J = mat_det(Ft);
         left_stretch(Ft, J, U, so);
         if (return_map_principal(material, so, J, mu, lam, ys, ms, dt, sn, rm1, t)) {
-            const Mat3 GF = mat_mul(mat_udut(U, rm1), Ft);
-            for (int i = 0; i < 9; ++i) F.m[i] = Ft.m[i] + GF.m[i];
+            const float amax = fmaxf(fmaxf(fabsf(so[0]), fabsf(so[1])), fabsf(so[2]));
+            const bool rank_deficient = !(fabsf(so[0]) > 1.0e-6f * amax) || !(fabsf(so[1]) > 1.0e-6f * amax) || !(fabsf(so[2]) > 1.0e-6f * amax);
+            if (rank_deficient) {
+                F = rebuild_rank_deficient(Ft, U, Vec3s{so[0], so[1], so[2]}, Vec3s{sn[0], sn[1], sn[2]}, amax);
+            } else {
+                const Mat3 GF = mat_mul(mat_udut(U, rm1), Ft);
+                for (int i = 0; i < 9; ++i) F.m[i] = Ft.m[i] + GF.m[i];
+            }
         }
         tau = mat_udut(U, t);
     } else {

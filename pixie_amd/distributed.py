@@ -92,11 +92,13 @@ def unpack_fields(buf: torch.Tensor, world: int, n_local: int, spatial: Tuple[in
     return cont, seg
 
 
-def all_gather_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def all_gather_fields(cont_pred: torch.Tensor, seg_pred: torch.Tensor, force_wire: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather the local scenes' fields with ONE collective on the packed 13 B/voxel buffer (two
     collectives -- fp32, then uint8 -- until round 3).  Returns tensors ordered rank-major: (world * n_local, 3, D, H, W) fp32
-    and (world * n_local, D, H, W) uint8.  With world == 1 (or no process group) nothing is packed or copied."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    and (world * n_local, D, H, W) uint8.  With world == 1 (or no process group) nothing is packed or copied -- unless
+    `force_wire`, which sends a one-rank group through pack kernel -> all_gather_into_tensor (uint8) -> unpack all the same (the
+    one-GPU test boxes' proof that the RCCL call, its dtype and the 16-byte alignment path are live)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_wire):
         return cont_pred.contiguous().to(torch.float32), seg_pred.contiguous().to(torch.uint8)
     world = dist.get_world_size()
     mine = pack_fields(cont_pred, seg_pred)

@@ -35,6 +35,16 @@ NAME_TO_MATERIAL_ID = {name: i for i, name in MATERIAL_ID_TO_NAME.items() if nam
 NAME_TO_MATERIAL_ID.update({"elastic": 0, "rigid": 6})
 
 
+# The reference prints its progress lines (mpm_solver_warp.py:280-281, :290-292) and so does the shim; a caller that creates
+# solvers in a loop (bench.py) switches them off with `pixie_amd.mpm_solver.VERBOSE = False`.
+VERBOSE = True
+
+
+def _say(*args):
+    if VERBOSE:
+        print(*args)
+
+
 def get_material_name(material_id):
     """mpm_solver_warp.py:29-39 -- despite its name the reference maps NAME -> id (or -1)."""
     return NAME_TO_MATERIAL_ID.get(material_id, -1)
@@ -277,8 +287,8 @@ class MPM_Simulator_WARP:
         if tensor_cov is not None:
             self.set_field("init_cov", tensor_cov.reshape(-1))
         # v = 0 and F_trial = I are the create() defaults (:262-277)
-        print("Particles initialized from torch data.")
-        print("Total particles: ", self.n_particles)
+        _say("Particles initialized from torch data.")
+        _say("Total particles: ", self.n_particles)
 
     def set_parameters(self, device="cuda:0", **kwargs):
         """:284-285"""
@@ -287,9 +297,9 @@ class MPM_Simulator_WARP:
     def set_parameters_dict(self, kwargs={}, device="cuda:0"):
         """:287-463"""
         if "material" in kwargs:
-            print("Setting material to ", kwargs["material"])
+            _say("Setting material to ", kwargs["material"])
             self._material = get_material_name(kwargs["material"])
-            print("Material ID: ", self._material)
+            _say("Material ID: ", self._material)
             if self._material == -1:
                 raise TypeError("Undefined material type")
         new_lim = kwargs.get("grid_lim", self.grid_lim)
@@ -679,6 +689,10 @@ def run_batch(solvers, dt, n_substeps, streams=None):
             if getattr(s, "_batch_stream", None) is None:
                 s._batch_stream = torch.cuda.Stream(dev)
             streams.append(s._batch_stream)
+    else:
+        streams = list(streams)
+        if len(streams) != len(solvers):    # (zip would silently skip the solvers without a stream: ADVICE r5)
+            raise ValueError(f"run_batch: {len(solvers)} solvers but {len(streams)} streams")
     errors = []
 
     def work(s, st):

@@ -91,6 +91,22 @@ def signed_distance(density: torch.Tensor) -> torch.Tensor:
     return torch.where(inside, _edt_squared(inside).double().sqrt() - 0.5, -(_edt_squared(~inside).double().sqrt() - 0.5))
 
 
+_SMOOTH_WARNED = False
+
+
+def _warn_smooth_unpinned():
+    """Once per process: `smooth=True` is the one step of this package whose reference (PyMCubes' mcubes.smooth, a third-party wheel
+    absent from the reference tree and from this image) could not be run against it -- a restatement of its published algorithm,
+    NOT parity-pinned ("Deviations").  custom_sand_config.json:39 and custom_rocks_config.json:40 set it."""
+    global _SMOOTH_WARNED
+    if not _SMOOTH_WARNED:
+        _SMOOTH_WARNED = True
+        import warnings
+        warnings.warn("pixie_amd.particle_filling: smooth=True runs a restatement of PyMCubes' constrained smoothing (mcubes.smooth is not available "
+                      "to compare against): this sub-step is not parity-pinned to the reference; every other step of fill_particles is.",
+                      RuntimeWarning, stacklevel=3)
+
+
 def smooth_constrained(density: torch.Tensor, max_iters: int = 500, rel_tol: float = 1e-6, band_radius: int = 4) -> torch.Tensor:
     """mcubes.smooth(df, method="constrained", max_iters=500) on the device (see the module docstring; the algorithm is
     stated step by step in the checker's `smooth_constrained` under tests' filling oracle).  Dense-grid form of the sparse system: with b the
@@ -178,6 +194,7 @@ def fill_particles(pos, opacity, cov, grid_n: int, max_samples: int, grid_dx: fl
     print("after dense grids: ", n_dense)
     search_field = density
     if smooth:    # filling.py:351-358: the internal filling reads the constrained-smoothed signed distance of the density's support
+        _warn_smooth_unpinned()
         search_field = smooth_constrained(density, max_iters=500).to(torch.float32).contiguous()
         print("smooth finished")
     check(lib.pixie_fill_internal_cells(_p(count), _p(search_field), int(grid_n), float(grid_dx), int(max_particles_per_cell), int(search_exclude_dir),

@@ -88,36 +88,40 @@ def neural_scene_batch(seg_network, cont_network, scenes, *, n_grid: int, grid_l
         except Exception as exc:
             errors.append(exc)
 
-    for i, (feat_grid, mask, particle_x, particle_vol) in enumerate(scenes):
-        dev = feat_grid.device
-        if dev.type != "cuda":
-            raise RuntimeError("neural_scene_batch runs on a HIP device only (no CPU fallback)")
-        if side is None:
-            cur = torch.cuda.current_stream(dev)
-            side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        with torch.no_grad():
-            combined, _, _, _ = predict_material_field(seg_network, cont_network, feat_grid)
-        solver = MPM_Simulator_WARP(10)
-        solver.load_initial_data_from_torch(particle_x, particle_vol, None, n_grid=n_grid, grid_lim=grid_lim)
-        solver.set_parameters_dict(params)
-        if configure is not None:
-            configure(solver)
-        apply_material_field_to_solver(solver, combined[0], mask, min_bounds, max_bounds, to_field_frame(particle_x.to(dev)),
-                                       k_smoothing_neighbors=k, nn_distance_threshold=nn_distance_threshold, ranges=ranges)
-        solver.flush()
-        st = side[i % 2]
-        if len(threads) >= 2:
-            threads[-2].join()          # the previous user of this side stream has issued all its launches
-        st.wait_stream(cur)             # set-up and field transfer of this scene are in front of its rollout
-        t = threading.Thread(target=roll, args=(solver, st))
-        t.start()
-        threads.append(t)
-        solvers.append(solver)
-    for t in threads:
-        t.join()
-    if side is not None:
-        for st in side:
-            cur.wait_stream(st)
+    # (an exception inside the loop -- the 10 %-too-far assertion of the field transfer, the device check, `configure` -- must
+    # not leave rollout threads running or the caller's stream unordered behind the side streams while their solvers are released)
+    try:
+        for i, (feat_grid, mask, particle_x, particle_vol) in enumerate(scenes):
+            dev = feat_grid.device
+            if dev.type != "cuda":
+                raise RuntimeError("neural_scene_batch runs on a HIP device only (no CPU fallback)")
+            if side is None:
+                cur = torch.cuda.current_stream(dev)
+                side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            with torch.no_grad():
+                combined, _, _, _ = predict_material_field(seg_network, cont_network, feat_grid)
+            solver = MPM_Simulator_WARP(10)
+            solver.load_initial_data_from_torch(particle_x, particle_vol, None, n_grid=n_grid, grid_lim=grid_lim)
+            solver.set_parameters_dict(params)
+            if configure is not None:
+                configure(solver)
+            apply_material_field_to_solver(solver, combined[0], mask, min_bounds, max_bounds, to_field_frame(particle_x.to(dev)),
+                                           k_smoothing_neighbors=k, nn_distance_threshold=nn_distance_threshold, ranges=ranges)
+            solver.flush()
+            st = side[i % 2]
+            if len(threads) >= 2:
+                threads[-2].join()          # the previous user of this side stream has issued all its launches
+            st.wait_stream(cur)             # set-up and field transfer of this scene are in front of its rollout
+            t = threading.Thread(target=roll, args=(solver, st))
+            t.start()
+            threads.append(t)
+            solvers.append(solver)
+    finally:
+        for t in threads:
+            t.join()
+        if side is not None:
+            for st in side:
+                cur.wait_stream(st)
     if errors:
         raise errors[0]
     return solvers

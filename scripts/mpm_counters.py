@@ -41,5 +41,11 @@ for path in sorted(glob.glob(os.path.join(src, "stats_*.csv"))):
     if blk:
         res.setdefault(key_of(scene), {}).update({"block_kernel_us": blk[1], "block_kernel_calls": blk[0], "grid_kernel_us": grd[1] if grd else None,
                                                   "stats_source": f"profiles/{tag}_stats_{scene}.csv"})
+import hashlib
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_sha = hashlib.sha256(open(os.path.join(_root, "pixie_amd/csrc/mpm.hip"), "rb").read()).hexdigest()[:16]
+_sha_math = hashlib.sha256(open(os.path.join(_root, "pixie_amd/csrc/mpm_math.h"), "rb").read()).hexdigest()[:16]
+for v in res.values():      # bench.py drops an entry whose kernel source has changed since the pass (bench.py: _fresh)
+    v.update({"source": "pixie_amd/csrc/mpm.hip", "source_sha16": _sha, "mpm_math_sha16": _sha_math})
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

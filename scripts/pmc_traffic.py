@@ -6,7 +6,17 @@ import json
 import re
 import sys
 
+import hashlib
+import os
+
 d, out = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCE = {"conv": "pixie_amd/csrc/conv3d_f16x3.hip", "mpm": "pixie_amd/csrc/mpm.hip"}   # the file each kernel lives in: bench.py drops an entry
+                                                                                         # whose source has changed since (source_sha16)
+
+
+def sha16(rel):
+    return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
 CAL_BYTES = 2 << 30
 
 
@@ -48,7 +58,8 @@ for tag, kernel, rd, wr in (("conv_64_64_128", "conv3d_f16x3_c64_fullres_kernel"
     if f is None or w is None or not fac.get(rd) or not fac.get(wr):
         res[tag] = None
         continue
-    res[tag] = {"fetch_counter_KiB": f, "write_counter_KiB": w, "read_bytes": f * 1024 * fac[rd], "write_bytes": w * 1024 * fac[wr],
+    src = SOURCE["mpm" if tag.startswith("mpm") else "conv"]
+    res[tag] = {"source": src, "source_sha16": sha16(src), "fetch_counter_KiB": f, "write_counter_KiB": w, "read_bytes": f * 1024 * fac[rd], "write_bytes": w * 1024 * fac[wr],
                 "hbm_bytes_per_launch": f * 1024 * fac[rd] + w * 1024 * fac[wr],
                 "correction": f"reads x{fac[rd]:.3f} ({rd}), writes x{fac[wr]:.3f} ({wr})"}
 json.dump(res, open(out, "w"), indent=1)

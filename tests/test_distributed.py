@@ -142,6 +142,30 @@ def test_rccl_process_group_and_graph_capture_coexist(hip_device):
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_rccl_wire_path_executes_on_one_rank(hip_device):
+    """no box of any round had two GPUs, so the device branch of the exchange -- pixie_pack_fields -> uint8
+    dist.all_gather_into_tensor under backend "nccl" (= RCCL) -> 16-byte-aligned unpack -- had never executed, not even with one rank
+    (all_gather_fields short-circuits at world 1).  `force_wire` sends a one-rank group through it, at the bench's 128^3 (and an odd
+    size, whose float block ends off a 16-byte boundary): the gathered fields must equal the inputs bit for bit.  Not a scaling
+    number; the proof that the call, dtype and alignment path run on RCCL."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        for n, shape in ((1, (128, 128, 128)), (2, (5, 7, 9))):
+            g = torch.Generator().manual_seed(n)
+            cont = torch.randn((n, 3) + shape, generator=g).to(hip_device)
+            seg = torch.randint(0, 8, (n,) + shape, generator=g, dtype=torch.int32).to(hip_device)
+            g_cont, g_seg = pd.all_gather_fields(cont, seg, force_wire=True)
+            torch.cuda.synchronize()
+            assert g_cont.data_ptr() != cont.data_ptr() and g_cont.is_cuda and g_seg.dtype == torch.uint8     # went through the wire buffer
+            assert torch.equal(g_cont, cont) and torch.equal(g_seg.to(torch.int32), seg)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_wire_format_round_trip_single_process():
     """pack -> (what all_gather_into_tensor does: concatenate the ranks' buffers) -> unpack, odd voxel counts included
     (the float32 block of every rank must stay 4-byte aligned inside the gathered buffer: 16-byte padding)."""

@@ -223,6 +223,77 @@ def test_device_stress_matches_oracle(material, scale, ys, inverted):
     assert np.allclose(mu, o.field("mu"), rtol=1e-6) and np.allclose(lam, o.field("lam"), rtol=1e-6)
 
 
+def _rot(rng, n):
+    q, _ = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+    q[np.linalg.det(q) < 0, :, 0] *= -1.0
+    return q
+
+
+@pytest.mark.parametrize("material,ys", [(1, 5e3), (5, 5e3), (3, 5e3), (2, 0.0)])
+@pytest.mark.parametrize("case", ["two_small_axes", "rank_deficient"])
+def test_crushed_and_rank_deficient_elements(case, material, ys):
+    """ADVICE r5, two holes of the single-decomposition constitutive path (mpm_math.h), on F_trial = U diag(sigma) V^T with random rotations:
+    `two_small_axes`: sigma = (1, 1e-2, 2e-2) x (1 +- 10 %).  The Jacobi iteration runs on F F^T, whose float32 entries resolve the frame of
+      the two small axes only to 1e-7 / (4e-4 - 1e-4) = 3e-4 rad; refine_crushed_frame finishes it on F itself.  Stress and F must meet the
+      bars of test_device_stress_matches_oracle's crushed cases against the float64 oracle (which runs the reference's two full SVDs).
+    `rank_deficient`: the smallest singular value EXACTLY zero (F_trial = U diag(s0, s1, 0) V^T assembled in float64, then the null direction
+      projected out in float32).  sigma'/sigma - 1 is infinite there: the correction form of the returned F gave NaN, which P2G spreads;
+      rebuild_rank_deficient re-assembles U diag(sigma') V^T like the reference (its max(sigma, 0.01) clamp).  Finite, and equal to the
+      float64 oracle's F where that is unique (one null axis)."""
+    lib = _harness.load()
+    rng = np.random.default_rng(77 + material)
+    n = 2000
+    U, V = _rot(rng, n), _rot(rng, n)
+    if case == "two_small_axes":
+        sig = np.array([1.0, 1e-2, 2e-2]) * rng.uniform(0.9, 1.1, (n, 3))
+    else:
+        sig = np.stack([rng.uniform(0.8, 1.2, n), rng.uniform(0.5, 0.9, n), np.zeros(n)], 1)
+    Ft = np.einsum("nij,nj,nkj->nik", U, sig, V).astype(np.float32)
+    if case == "rank_deficient":    # make the float32 matrix singular to rounding: remove what the cast left along the null direction
+        Ft = (Ft.astype(np.float64) - np.einsum("ni,nj->nij", np.einsum("nij,nj->ni", Ft.astype(np.float64), V[:, :, 2]), V[:, :, 2])).astype(np.float32)
+    Ft = np.ascontiguousarray(Ft)
+    sc = mpm_ball_scene(n, seed=1)
+    sc["bcs"] = []; sc["fix_ground"] = None
+    o, o32 = make_oracle(sc, "f64"), make_oracle(sc, "f32")
+    for oo in (o, o32):
+        apply_scene(oo, sc)
+        oo.field("F_trial")[:] = Ft
+        oo.field("material")[:] = material
+        oo.field("yield_stress")[:] = ys
+        oo._lib.mpm_set_scalar(oo._h, b"hardening", 1.0)
+        oo._lib.mpm_set_scalar(oo._h, b"xi", 0.05)
+        oo._lib.mpm_set_scalar(oo._h, b"plastic_viscosity", 10.0)
+        oo.finalize_mu_lam_bulk()
+    mu, lam, bulk, ysv = (o.field(f).astype(np.float32) for f in ("mu", "lam", "bulk", "yield_stress"))
+    mat = np.full(n, material, np.int32)
+    F = np.zeros((n, 3, 3), np.float32); tau = np.zeros((n, 3, 3), np.float32)
+    alpha = float(np.sqrt(2 / 3) * 2 * np.sin(25 / 180 * 3.14159265) / (3 - np.sin(25 / 180 * 3.14159265)))
+    lib.hh_stress(n, mat.ctypes.data, Ft.ctypes.data, mu.ctypes.data, lam.ctypes.data, bulk.ctypes.data, ysv.ctypes.data,
+                  alpha, 1.0, 0.05, 0.1, 10.0, 1e-4, F.ctypes.data, tau.ctypes.data)
+    o.phase("compute_stress", 1e-4); o32.phase("compute_stress", 1e-4)
+    ok = np.isfinite(o.field("F")).reshape(n, -1).all(1) & np.isfinite(o.field("stress")).reshape(n, -1).all(1)
+    # (Drucker-Prager on an F that does NOT yield keeps sigma = 0 and takes its logarithm -- in the reference's own formula, mpm_utils.py:71-86;
+    # every other law clamps.  The product must be finite wherever the reference's algorithm is.)
+    # A singular F is outside that law's domain: whether its SVD returns 0 or 1e-9 for the null axis decides between -inf and a finite
+    # garbage value, in the reference, in either oracle and in the product alike -- there only F must stay finite and the comparison runs
+    # over the particles where all three stresses are finite.)
+    assert np.isfinite(F).all()
+    if material == 2:
+        ok = ok & np.isfinite(tau).reshape(n, -1).all(1) & np.isfinite(o32.field("stress")).reshape(n, -1).all(1)
+    assert np.isfinite(tau[ok]).all(), int((~np.isfinite(tau[ok])).sum())
+    assert ok.all() or material == 2
+    scale_tau = max(np.abs(o.field("stress")[ok]).max(), 1e-30)
+    e_F, d_F = rel_l2(F[ok], o.field("F")[ok]), rel_l2(o32.field("F")[ok], o.field("F")[ok])
+    e_t = np.abs(tau[ok] - o.field("stress")[ok]).max() / scale_tau
+    d_t = np.abs(o32.field("stress")[ok] - o.field("stress")[ok]).max() / scale_tau
+    moved = float((np.abs(o.field("F")[ok] - Ft[ok]).reshape(int(ok.sum()), -1).max(1) > 1e-7).mean())
+    print(f"{case}, material {material}: {100 * moved:.0f} % moved, {int(ok.sum())} of {n} finite in the float64 oracle; "
+          f"F {e_F:.1e} (float32 oracle {d_F:.1e}), stress {e_t:.1e} of max (float32 oracle {d_t:.1e})")
+    assert ok.sum() > 0.5 * n or material == 2
+    if ok.any():
+        assert e_F < max(5e-6, 1.5 * d_F) and e_t < max(5e-5, 1.5 * d_t)
+
+
 def test_polar_iteration_converges_with_and_without_scaling():
     """polar_rotation (mpm_math.h, host build) over the whole range it is used on: nearly rigid inputs, the strains of a stable
     simulation, singular values from 0.15 to 3.  The iteration must settle within its six steps and give the polar factor U V^T
