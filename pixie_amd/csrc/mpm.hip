@@ -381,6 +381,19 @@ __device__ __forceinline__ void preload_particle(const MpmPtrs& S, int p, Preloa
     }
 }
 
+// What a caller reads from a particle that has just been frozen outside the grid: zero velocity and APIC matrix, and its last
+// deformation gradient as F_trial.  (The fused kernel keeps v, C and F_trial of the particles that take part in registers, and a
+// re-binning does not move those rows for them -- bin_permute_kernel -- so the rows of a particle that drops out are written here.)
+// (inlined, a rolled loop of plain stores: an out-of-line function taking the kernel's parameter struct by reference copies it to
+// scratch -- 404 -> 740 bytes per lane, beyond the cliff of profiles/r6e_scratch_regression.txt)
+__device__ __forceinline__ void freeze_particle_state(const MpmPtrs& S, int p, const Mat3& F) {
+    const int n = S.n;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) S.v[d * n + p] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { S.C[i * n + p] = 0.0f; S.Ft[i * n + p] = F.m[i]; }
+}
+
 template <bool DO_G2P, bool DO_P2G, bool SCHED>
 __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepParams& sp, const PModSet& pms, int p, int ox, int oy,
                                                 int oz, const float4* tv, const Preload& L, ScatterIn& out) {
@@ -397,6 +410,7 @@ __device__ __forceinline__ void particle_phase1(const MpmPtrs& S, const StepPara
         if (!stencil_inside(st, S.ng)) {
             atomicAdd(S.oob, 1ull);
             S.selection[p] = 2;   // left the grid: frozen from now on and counted once (UB in the reference)
+            freeze_particle_state(S, p, L.F);
             return;
         }
         const Mat3& Fold = L.F;
@@ -688,6 +702,10 @@ __global__ __launch_bounds__(kWG, OCC) void mpm_block_kernel(MpmPtrs S, StepPara
         if (!stencil_inside(st, ng)) {
             atomicAdd(S.oob, 1ull);
             S.selection[it.y + q] = 2;
+            Mat3 Fnow;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Fnow.m[i] = S.F[i * S.n + it.y + q];     // (the return-mapped F this launch has just stored)
+            freeze_particle_state(S, it.y + q, Fnow);
             in.active = false;
         } else {
             const int lx = st.base[0] - ox, ly = st.base[1] - oy, lz = st.base[2] - oz;
@@ -837,19 +855,27 @@ __global__ __launch_bounds__(256) void bin_count_kernel(MpmPtrs S, int* __restri
         for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off, 64));
         if ((threadIdx.x & 63) == 0 && d2 > __uint_as_float(*drift2_bits)) atomicMax(drift2_bits, __float_as_uint(d2));
     }
+    // Two groups of a wave share one atomic each -- the key of its first lane and the key of the first lane outside that group (binned
+    // particles arrive block by block: a wave rarely spans more) -- and whoever is left takes its own.  All of a wave's atomics are
+    // then in flight within three round trips; until round 6 every distinct key of the wave cost a dependent one (a scene in motion:
+    // 4-6 per wave, 99 us for 1 M particles).  The arrival number is arbitrary either way; bin_local_order_kernel makes the order a
+    // function of the particle data.
     const int lane = threadIdx.x & 63;
     int my_rank = 0;
     unsigned long long todo = __ballot(valid);
-    while (todo) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (!todo) break;
         const int leader = __ffsll((long long)todo) - 1;
         const int k = __shfl(key, leader);
         const unsigned long long grp = __ballot(valid && key == k) & todo;
         int base = 0;
         if (lane == leader) base = atomicAdd(&counts[k], __popcll(grp));
         base = __shfl(base, leader);
-        if (valid && key == k && ((grp >> lane) & 1ull)) my_rank = base + __popcll(grp & ((1ull << lane) - 1ull));
+        if ((grp >> lane) & 1ull) my_rank = base + __popcll(grp & ((1ull << lane) - 1ull));
         todo &= ~grp;
     }
+    if ((todo >> lane) & 1ull) my_rank = atomicAdd(&counts[key], 1);
     if (valid) { keys[p] = key; rank[p] = my_rank; }
 }
 
@@ -1062,13 +1088,20 @@ __global__ __launch_bounds__(256) void bin_mark_active_kernel(const int* __restr
 }
 
 // dst[r][q] = src[r][order[q]] for every row of the particle word array
+// `skip_vcft`: the launch this re-binning precedes starts with a G2P, which overwrites v, C and F_trial of every particle that takes
+// part (in the fused kernel they are not even stored between the gather and the scatter) -- 21 of the 51 rows are dead for those
+// particles and only travel for the ones that sit out (selection != 0: deselected by the caller or frozen outside the grid), whose
+// last stored values a caller may still read.
 __global__ __launch_bounds__(256) void bin_permute_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
-                                                          const int* __restrict__ order, int n, int rows_per_y) {
+                                                          const int* __restrict__ order, int n, int rows_per_y, int skip_vcft) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     const int p = order[q];
     const int r0 = blockIdx.y * rows_per_y, r1 = min(r0 + rows_per_y, (int)R_COUNT);
+    const bool sits_out = skip_vcft && src[(size_t)R_SELECTION * n + p] != 0u;
     for (int r = r0; r < r1; ++r) {
+        const bool dead = skip_vcft && ((r >= R_V && r < R_V + 3) || (r >= R_FT && r < R_FT + 9) || (r >= R_C && r < R_C + 9));
+        if (dead && !sits_out) continue;
         const int rs = (r >= R_XREF) ? (R_X + r - R_XREF) : r;   // xref <- x: positions at this re-binning
         dst[(size_t)r * n + q] = src[(size_t)rs * n + p];
     }
@@ -1645,7 +1678,7 @@ void build_work_list(pixie_mpm* h, hipStream_t st) {
 
 // Re-bin the particles by grid block (counting sort) and rebuild the work list.  Everything runs on the device;
 // the host only waits for the 4-byte item count so that the block kernel gets an exact grid.
-int rebin(pixie_mpm* h, hipStream_t st) {
+int rebin(pixie_mpm* h, hipStream_t st, bool g2p_follows = false) {
     MpmPtrs& S = h->S;
     const int n = S.n;
     // Work-item capacity: 256 particles (one per thread).  128-thread items were measured too (set_scalar "item_cap"):
@@ -1668,7 +1701,7 @@ int rebin(pixie_mpm* h, hipStream_t st) {
                        h->rank, h->order2);
     const int rows_per_y = 9;
     hipLaunchKernelGGL(bin_permute_kernel, dim3(cdiv(n, 256), cdiv(R_COUNT, rows_per_y)), dim3(256), 0, st,
-                       h->words[h->cur], h->words[h->cur ^ 1], h->order2, n, rows_per_y);
+                       h->words[h->cur], h->words[h->cur ^ 1], h->order2, n, rows_per_y, g2p_follows ? 1 : 0);
     PX_CHECK_HIP(hipGetLastError());
     const bool measure_mass = h->mass_range_dirty;
     if (measure_mass) {
@@ -1862,7 +1895,7 @@ std::vector<PModDev> active_pmods(const pixie_mpm* h, float time) {
 int launch_particle(pixie_mpm* h, bool g2p, bool p2g, const StepParams& sp, hipStream_t st) {
     // (never while staged tiles are waiting for the grid kernel: the work list they are indexed by must not change)
     if (!h->pending_p2g && (h->needs_sort || (h->resort_interval > 0 && h->steps_since_sort >= h->resort_interval)))
-        if (rebin(h, st)) return 1;
+        if (rebin(h, st, g2p)) return 1;
     if (g2p) ++h->steps_since_sort;
     const int blocks = cdiv(h->S.n, 256);
     const dim3 grid((unsigned)std::max(h->n_items, 1));

@@ -973,6 +973,40 @@ def test_tiny_and_degenerate_scenes(hip_device):
     assert np.isfinite(h.get_field("grid_v_out").cpu().numpy()).all()
 
 
+def test_particles_leaving_the_grid_freeze_with_a_defined_state(hip_device):
+    """A particle whose stencil leaves the grid is undefined behaviour in the reference (out-of-range grid indices).  Here it is frozen where
+    it is (selection 2), counted once, and -- since the fused kernel keeps v, C and F_trial of active particles in registers and a
+    re-binning no longer moves those rows for them -- given a defined observable state: v = 0, C = 0, F_trial = its last F.  Everything
+    stays finite, the rest of the scene goes on, and re-binnings in between (forced) do not scramble the frozen rows."""
+    sc = mpm_ball_scene(20000, seed=5, scenario="ball")
+    sc["bcs"] = []                                  # no bounding box: nothing stops them
+    sc["params"] = dict(sc["params"], g=[0.0, 0.0, 0.0])
+    fast = np.arange(20000) % 50 == 0               # 400 particles taken out of the ball and put in a sheet 0.2 from the +x wall, flying at it
+    rng = np.random.default_rng(3)
+    sc["x"] = sc["x"].copy()
+    sc["x"][fast] = np.stack([np.full(400, 1.75), rng.uniform(0.6, 1.4, 400), rng.uniform(0.6, 1.4, 400)], 1).astype(np.float32)
+    h = make_hip(sc)
+    v0 = np.zeros((20000, 3), np.float32)
+    v0[fast] = [25.0, 0.0, 0.0]                     # 0.06 cells per substep: the stencil leaves the grid at x = 1.94 after ~75 substeps
+    h.set_field("v", v0)
+    h._set_scalar("resort_interval", 4)
+    h.run(sc["dt"], 300)
+    sel = get(h, "selection").reshape(-1)
+    gone = sel == 2
+    print(f"{int(gone.sum())} particles left the grid, {int(h._get_scalar('n_rebins'))} re-binnings, dropped {h._get_scalar('dropped_particles'):.0f}")
+    assert h.out_of_bounds == int(gone.sum()) + int(h._get_scalar("dropped_particles")) and int(gone.sum()) == 400 and int(h._get_scalar("n_rebins")) > 10
+    assert np.array_equal(gone, fast)
+    x, v, C, Ft, F = (get(h, f) for f in ("x", "v", "C", "F_trial", "F"))
+    for a in (x, v, C, Ft, F):
+        assert np.isfinite(a).all()
+    assert np.abs(v[gone]).max() == 0.0 and np.abs(C[gone]).max() == 0.0
+    assert np.array_equal(Ft[gone], F[gone]) and np.abs(np.linalg.det(Ft[gone].reshape(-1, 3, 3)) - 1.0).max() < 0.5
+    assert (np.abs(x[gone] - 1.0).max(1) > 0.8).all()     # frozen at a wall, where they left
+    h.run(sc["dt"], 50)                             # and stay exactly there
+    assert np.array_equal(get(h, "x")[gone], x[gone]) and np.abs(get(h, "v")[gone]).max() == 0.0
+    assert int((get(h, "selection").reshape(-1) == 2).sum()) >= int(gone.sum())
+
+
 def test_work_item_capacity_follows_the_scene_density(hip_device):
     """item_cap "auto": 256-thread work items in dense scenes, 128-thread ones -- from the FIRST binning on: the choice is made from that
     binning's own block histogram -- where few blocks hold more than 128 particles (<= 15 % more work items; a 256-thread workgroup then
