@@ -482,7 +482,7 @@ def _fresh(entries):
 
 def load_traffic():
     """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE in
-    separate passes, corrected with calibration kernels of the same access widths, scripts/gpu_pmc.sh).  PMC counters
+    separate passes, corrected with calibration kernels of the same access widths, scripts/sessions/gpu_pmc.sh).  PMC counters
     cannot be collected from inside this process, so `traffic` is the profile's reading for the same kernel + shape -- if it was
     taken from the current source of that kernel (_fresh), else None."""
     try:

@@ -49,7 +49,7 @@ timeout 1200 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/benc
 echo "bench exit $?" >> $OUT/bench.err
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --mpm-substeps 300 > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof_bench.err)
 timeout 300 python scripts/unet_exec_bench.py 16 32 64 128 2>/dev/null | grep "D=" > $OUT/unet_exec_bench.txt
-bash scripts/gpu_conv_wino.sh $TAG > /dev/null 2>&1
+bash scripts/sessions/gpu_conv_wino.sh $TAG > /dev/null 2>&1
 DB=$(find $OUT/prof -name "*.db" | head -1)
 [ -n "$DB" ] && python scripts/rocpd_stats.py $DB $OUT/kernel_stats.csv
 rm -rf $OUT/prof
