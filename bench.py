@@ -475,7 +475,8 @@ def _fresh(entries):
     entry that predates the last change to that file is dropped -- the line then prints `traffic: null` instead of a stale reading."""
     out = {}
     for k, v in (entries or {}).items():
-        if isinstance(v, dict) and v.get("source") and v.get("source_sha16") == _source_sha16(v["source"]):
+        if isinstance(v, dict) and v.get("source") and v.get("source_sha16") == _source_sha16(v["source"]) and \
+                (v.get("mpm_math_sha16") is None or v["mpm_math_sha16"] == _source_sha16("pixie_amd/csrc/mpm_math.h")):
             out[k] = v
     return out
 
