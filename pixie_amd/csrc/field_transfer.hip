@@ -111,7 +111,11 @@ __global__ __launch_bounds__(128) void field_knn_kernel(FieldArgs A) {
     long bi[kMaxK];
     int cnt = 0;
     const int K = A.k;
-    const int rmax = max(max(A.D, A.H), A.W);
+    // Fewer occupied voxels than K in the whole field (an empty or nearly empty mask): no particle can collect K neighbours, and
+    // looking for them would walk the entire lattice once per particle (2 M voxels x 100 k particles at 128^3).  sums[4] = the number
+    // of occupied voxels (field_defaults_kernel, the launch before this one): everyone takes the defaults below at once.
+    // (sklearn raises there -- "Expected n_neighbors <= n_samples_fit" -- and so does pixie_amd.material_field's host-level entry.)
+    const int rmax = (A.sums[4] >= (double)K) ? max(max(A.D, A.H), A.W) : -1;
     for (int r = 0; r <= rmax; ++r) {
         for (int ix = max(cx - r, 0); ix <= min(cx + r, A.D - 1); ++ix) {
             const int adx = abs(ix - cx);

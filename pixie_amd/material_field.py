@@ -69,6 +69,7 @@ def field_to_particles(pred: torch.Tensor, mask: torch.Tensor, min_bounds: Seque
                                        p(out["material_id"]), p(out["part_labels"]), p(out["conf"]), p(out["nearest_dist"]),
                                        p(scratch), _lib.current_stream_ptr()), "pixie_field_to_particles")
     out["n_too_far"] = scratch[5:6].view(torch.int64)[0]
+    out["n_occupied_voxels"] = scratch[4]      # (0-d float64, device) how many voxels the mask keeps: fewer than k => every particle got the defaults
     return out
 
 
@@ -83,6 +84,10 @@ def apply_material_field_to_solver(mpm_solver, pred: torch.Tensor, mask: torch.T
     res = field_to_particles(pred, mask, min_bounds, max_bounds, particle_pos_field_frame, k_smoothing_neighbors,
                              nn_distance_threshold, weighted_assignment, ranges=ranges)   # ranges: the dataset's normalization_ranges.yaml (default: the shipped one)
     n = particle_pos_field_frame.shape[0]
+    n_vox = int(res["n_occupied_voxels"])
+    if n_vox < int(k_smoothing_neighbors):     # what sklearn's NearestNeighbors.kneighbors raises inside perform_knn_smoothing (material_field.py:228-300)
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {int(k_smoothing_neighbors)}, n_samples_fit = {n_vox}, "
+                         f"n_samples = {n}")
     n_far = int(res["n_too_far"])
     assert n_far <= 0.1 * n, (f"[CRITICAL] More than 10% of particles are too far from nearest neighbor. "
                               f"Distance threshold: {nn_distance_threshold}.")

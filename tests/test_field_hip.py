@@ -84,3 +84,34 @@ def test_full_size_and_solver_handoff(hip_device):
     conf = apply_material_field_to_solver(s, pred.to(hip_device), mask.to(hip_device), [-1, -1, -1], [1, 1, 1], pos.to(hip_device))
     assert conf.shape == (n,)
     assert torch.allclose(s.get_field("E").cpu(), out["E"].cpu()) and torch.equal(s.get_field("material").cpu(), mid)
+
+
+def test_empty_and_nearly_empty_masks(hip_device):
+    """Edge of the field -> particle transfer: a mask that keeps no voxel, or fewer than k.  sklearn's NearestNeighbors -- the reference's
+    perform_knn_smoothing, material_field.py:228-300 -- raises there; the host-level entry raises the same ValueError, and the device-resident
+    entry hands every particle the defaults (n_too_far = n) WITHOUT walking the lattice once per particle (a 128^3 field and 100 k
+    particles: this test would not finish otherwise)."""
+    import time
+    from pixie_amd.material_field import apply_material_field_to_solver, field_to_particles
+    from pixie_amd.mpm_solver import MPM_Simulator_WARP
+    D, n = 128, 100_000
+    gen = torch.Generator().manual_seed(3)
+    pred = torch.zeros((11, D, D, D))
+    pred[:3] = torch.randn((3, D, D, D), generator=gen) * 0.5
+    pred[3] = 1.0
+    pos = (torch.rand((n, 3), generator=gen) - 0.5)
+    for kept in (0, 4):
+        mask = torch.zeros((D, D, D))
+        mask.view(-1)[torch.randperm(D ** 3, generator=gen)[:kept]] = 1.0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = field_to_particles(pred.to(hip_device), mask.to(hip_device), [-1, -1, -1], [1, 1, 1], pos.to(hip_device), k=10)
+        assert int(out["n_too_far"]) == n and int(out["n_occupied_voxels"]) == kept
+        assert time.perf_counter() - t0 < 5.0
+        for key in ("density", "E", "nu", "conf"):
+            assert torch.isfinite(out[key]).all()
+        assert int(out["material_id"].min()) == int(out["material_id"].max())      # the default material for everyone
+        s = MPM_Simulator_WARP(10)
+        s.load_initial_data_from_torch(pos + 1.0, torch.full((n,), 1e-6), n_grid=50, grid_lim=2.0)
+        s.set_parameters_dict(dict(material="jelly", E=1e5, nu=0.3, density=1000.0))
+        with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+            apply_material_field_to_solver(s, pred.to(hip_device), mask.to(hip_device), [-1, -1, -1], [1, 1, 1], pos.to(hip_device))
