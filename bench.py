@@ -535,7 +535,7 @@ def bench_mpm(args, rank, world, device, particles, n_grid, substeps, tag, scatt
     s = _mpm_solver(sc, scatter_bits)
     if v0_rms:   # a scene in motion (strains of a few per cent): the block kernel's polar iteration then takes 2-3 steps per particle, not 1
         s.import_particle_v_from_torch(v0_rms * torch.randn((particles, 3), generator=torch.Generator().manual_seed(1 + rank)))
-    s.run(sc["dt"], 300 if v0_rms else 50)  # warm-up (includes the cautious first re-binning intervals)
+    s.run(sc["dt"], 300 if v0_rms else 100)  # warm-up: through the cautious first re-binning intervals (4, 16, 64 substeps) -- what scripts/mpm_bench.py does
     barrier_sync(world)
     t0 = time.perf_counter()
     s.run(sc["dt"], substeps)
