@@ -240,7 +240,7 @@ def test_bench_line_of_a_full_run_fits_the_drivers_record():
     import importlib.util
     import json
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(repo, "profiles", "bench_detail_r5last.json")
+    path = os.path.join(repo, "profiles", "bench_detail_r6last_full.json")   # (the --full record: every leg)
     if not os.path.exists(path):
         pytest.skip("no committed bench detail")
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(repo, "bench.py"))
@@ -256,6 +256,9 @@ def test_bench_line_of_a_full_run_fits_the_drivers_record():
     assert line["vs_baseline"] is None and "workload" in line["config"]
     for leg in ("sand", "snow", "metal", "mixed"):
         for f in ("us_per_substep", "frac_dense", "frac_touched", "valu_per_wave", "block_us_rocprofv3"):
+            if leg == "sand" and f == "frac_dense":      # n_grid 200: the dense-grid figure counts 8 M mostly empty cells and is not quoted
+                assert line["mpm_1m_sand_frac_dense"] is None
+                continue
             assert isinstance(line[f"mpm_1m_{leg}_{f}"], (int, float)), (leg, f)
     for k in ("mpm_floor_us", "mpm_frac_of_floor", "pipeline_ms_per_scene", "mpm_1m_frac_touched", "mpm_1m_frac_dense"):
         assert isinstance(line[k], (int, float)), k
