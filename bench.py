@@ -507,9 +507,13 @@ def load_counters():
 
 def _mpm_solver(sc, scatter_bits=None, wide=None, diag=False):
     from pixie_amd.mpm_solver import MPM_Simulator_WARP
-    s = MPM_Simulator_WARP(10, diag=diag)
+    # THIS rank's GPU (main() made it current): the reference's signature defaults to "cuda:0", which under N ranks would put every
+    # rank's solver on GPU 0 (found in round 6 by reading, not by running: no multi-GPU node has been available)
+    dev = f"cuda:{torch.cuda.current_device()}"
+    s = MPM_Simulator_WARP(10, device=dev, diag=diag)
     s.load_initial_data_from_torch(torch.from_numpy(sc["x"]), torch.from_numpy(sc["vol"]), torch.from_numpy(sc["cov"]),
-                                   n_grid=sc["n_grid"], grid_lim=sc["grid_lim"])
+                                   n_grid=sc["n_grid"], grid_lim=sc["grid_lim"], device=dev)
+    assert s.device.index == torch.cuda.current_device()
     if "F0" in sc:    # a plastic scene: the reference's config + a perturbed start, so that the return mappings work from substep 1
         start_plastic(s, sc, lambda f, a: s.set_field(f, a.reshape(a.shape[0], -1)))
     else:

@@ -47,8 +47,9 @@ def neural_scene_rollout(seg_network, cont_network, feat_grid: torch.Tensor, mas
         combined, _, _, _ = predict_material_field(seg_network, cont_network, feat_grid)     # inference_combined.py:122-126,186-195
     pred = combined[0]
     mark(1)
-    solver = MPM_Simulator_WARP(10)                                                            # gs_simulation.py:483-489
-    solver.load_initial_data_from_torch(particle_x, particle_vol, particle_cov, n_grid=n_grid, grid_lim=grid_lim)
+    dev = str(feat_grid.device)      # the GPU the field lives on (one process per GPU: not necessarily the signature's default "cuda:0")
+    solver = MPM_Simulator_WARP(10, device=dev)                                                # gs_simulation.py:483-489
+    solver.load_initial_data_from_torch(particle_x, particle_vol, particle_cov, n_grid=n_grid, grid_lim=grid_lim, device=dev)
     solver.set_parameters_dict(params)
     if configure is not None:
         configure(solver)
@@ -100,8 +101,8 @@ def neural_scene_batch(seg_network, cont_network, scenes, *, n_grid: int, grid_l
                 side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
             with torch.no_grad():
                 combined, _, _, _ = predict_material_field(seg_network, cont_network, feat_grid)
-            solver = MPM_Simulator_WARP(10)
-            solver.load_initial_data_from_torch(particle_x, particle_vol, None, n_grid=n_grid, grid_lim=grid_lim)
+            solver = MPM_Simulator_WARP(10, device=str(dev))
+            solver.load_initial_data_from_torch(particle_x, particle_vol, None, n_grid=n_grid, grid_lim=grid_lim, device=str(dev))
             solver.set_parameters_dict(params)
             if configure is not None:
                 configure(solver)
