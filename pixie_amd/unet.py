@@ -601,12 +601,15 @@ class _PixieUNet(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda" or feat_grid.device != dev:
             raise _lib.PixieHipError("model and input must live on the same HIP device (no CPU fallback)")
-        self._prepare(dev)
-        x = feat_grid.detach().to(torch.float32).contiguous()
-        if self.use_graph and taps is None:
-            return torch.stack([self._forward_graphed(x[n]) for n in range(x.shape[0])], dim=0)
-        outs = [self._forward_one(x[n], taps=taps if n == 0 else None) for n in range(x.shape[0])]
-        return torch.stack(outs, dim=0)
+        # the library launches on the CURRENT device's stream: make the model's device current for the call, as torch's own modules
+        # effectively do (a caller that never called torch.cuda.set_device(rank) would otherwise launch on GPU 0 with GPU-k pointers)
+        with torch.cuda.device(dev):
+            self._prepare(dev)
+            x = feat_grid.detach().to(torch.float32).contiguous()
+            if self.use_graph and taps is None:
+                return torch.stack([self._forward_graphed(x[n]) for n in range(x.shape[0])], dim=0)
+            outs = [self._forward_one(x[n], taps=taps if n == 0 else None) for n in range(x.shape[0])]
+            return torch.stack(outs, dim=0)
 
     def _prepare(self, dev) -> None:
         """(Re)bind the executors to the current parameters, device and precision."""
@@ -791,6 +794,9 @@ def predict_material_field(seg_network: SegmentationUNet, cont_network: Regressi
     """The compute of process_batch + save_predictions (trainer/inference_combined.py:122-126,186-195):
     returns (combined (N, 3+num_classes, D, H, W), seg_pred (N, D, H, W) int32, seg_logits, cont_pred).
     `dual_stream`: the two networks on two HIP streams; default: see _dual_stream_default."""
+    if feat_grid.is_cuda and feat_grid.device.index != torch.cuda.current_device():
+        with torch.cuda.device(feat_grid.device):      # (launches go to the current device's stream: see forward())
+            return predict_material_field(seg_network, cont_network, feat_grid, dual_stream)
     if dual_stream is None:
         dual_stream = _dual_stream_default(seg_network, cont_network, int(feat_grid[0, 0].numel()))
     if dual_stream and feat_grid.is_cuda:
