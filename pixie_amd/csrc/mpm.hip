@@ -67,6 +67,7 @@ struct MpmPtrs {
     const int4* items;           // work list: (block id, first slot, count, 0)
     float4* part;                // [n_items][kTN]: (m*v.xyz, m) of each work item's tile, written by its P2G
     unsigned long long* tile_mask;  // [n_items][8]: bit t of a tile = "node t (tile coordinates, z fastest) is not all zero"
+    unsigned zero_off;           // index (float4 units) of an all-zero tile behind the work items' tiles: what a gather reads where there is nothing to read
     int sparse_tiles;            // 1: P2G stores only the non-zero nodes of a tile and the grid kernel reads only those (masks);
                                  // 0: whole tiles both ways (scenes too small to be bandwidth-bound: one dependent load fewer)
     const int2* blk_items;       // per block: (first work item, number of work items)
@@ -1178,65 +1179,89 @@ __device__ __forceinline__ int2 neighbour_items(const MpmPtrs& S, int Bx, int By
     }
     return mine;
 }
-// RB = items per candidate block fetched in one go (8 x RB tile loads in flight)
+// One axis of staged_index: tile coordinate t -> (first node of its sub-box, nodes in the sub-box, t - first)
+__device__ __forceinline__ void staged_axis(int t, int& o, int& n, int& r) {
+    o = (t == 0) ? 0 : (t <= 4 ? 1 : 5);
+    n = (t == 0) ? 1 : (t <= 4 ? 4 : 3);
+    r = t - o;
+}
+// RB = items per candidate block fetched in one go (8 x RB tile loads in flight).
+//
+// Round 6: this gather was written as if the grid kernel were latency-bound, and its counters say otherwise -- 816 VALU instructions per
+// wave for ~10 float4 additions per lane: 3.7 waves per SIMD x 1.5 us of VALU issue at 1 M, FIFTEEN waves per SIMD on the reference's sand
+// configuration (15 700 active blocks: 21 of the launch's 21 us).  What it spent them on: staged_index per candidate (~30 selects x 8), a
+// branch + four zeroing moves around every predicated load, 64-bit address arithmetic, a 64-bit `live` word assembled bit by bit.  Now:
+// staged_index taken apart by axis (six small selects per axis and side, ~6 multiply-adds per candidate); 32-bit element offsets from
+// uniform bases; and NO predication -- a load that has nothing to fetch reads the all-zero tile at S.zero_off (or mask word 0, whose
+// value is then ignored), so every lane issues the same 8 x RB loads and adds what comes back.  Adding +0 changes nothing and the order of
+// the sum is still (round, candidate) whatever RB: every instantiation returns the bits it returned before.
+// (Round 4 tried issuing the first round's tile loads TOGETHER with the mask loads and dropping unstored nodes afterwards --
+// one dependent round trip fewer: 12.7 -> 15.5 us per launch at 1 M, the extra requests cost more than the trip saves;
+// profiles/r4f_mpm_grid_speculative_tile_loads_rejected.txt.  The loads added here all hit ONE line.)
 template <int RB>
 __device__ __forceinline__ float4 gather_node(const MpmPtrs& S, int2 mine, int lx, int ly, int lz, float4 acc) {
     const int ax = (lx == 3) ? 0 : -1, ay = (ly == 3) ? 0 : -1, az = (lz == 3) ? 0 : -1;  // first candidate offset per axis
-    unsigned off[8];   // in float4 units from S.part: first item * kTN + staged position of this node in that block's tiles
-    int cb[8];         // items of the candidate block << 16 | this node's number in the tile (mask bit)
+    // this node inside the tiles of the two candidate blocks per axis: coordinates t0 and t0 - 4
+    const int t0x = lx - 4 * ax + 1, t0y = ly - 4 * ay + 1, t0z = lz - 4 * az + 1;
+    int ox[2], nx[2], rx[2], oy[2], ny[2], ry[2], oz[2], nz[2], rz[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        staged_axis(t0x - 4 * b, ox[b], nx[b], rx[b]);
+        staged_axis(t0y - 4 * b, oy[b], ny[b], ry[b]);
+        staged_axis(t0z - 4 * b, oz[b], nz[b], rz[b]);
+    }
+    const int src0 = (ax + 1) * 9 + (ay + 1) * 3 + (az + 1);
+    unsigned toff[8];  // in float4 units from S.part: first item * kTN + staged position of this node in that block's tiles
+    unsigned moff[8];  // in 32-bit words from S.tile_mask: first item * 16 + the word that holds this node's bit
+    int sh[8];         // ... and the bit inside it
+    int nit[8];        // items of the candidate block
     int maxc = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const int dx = ax + (c >> 2), dy = ay + ((c >> 1) & 1), dz = az + (c & 1);
-        const int src = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
+        const int bx = c >> 2, by = (c >> 1) & 1, bz = c & 1;
+        const int src = src0 + bx * 9 + by * 3 + bz;
         const int first = __shfl(mine.x, src), n = __shfl(mine.y, src);
-        const int tx = lx - 4 * dx + 1, ty = ly - 4 * dy + 1, tz = lz - 4 * dz + 1;  // this node inside that block's tile
-        off[c] = (unsigned)first * kTN + (unsigned)staged_index(tx, ty, tz);
-        cb[c] = (n << 16) | ((tx * kTS + ty) * kTS + tz);
+        const int bit = ((t0x - 4 * bx) * kTS + (t0y - 4 * by)) * kTS + (t0z - 4 * bz);
+        const int si = ox[bx] * 64 + nx[bx] * (oy[by] * 8 + ny[by] * oz[bz]) + (rx[bx] * ny[by] + ry[by]) * nz[bz] + rz[bz];   // = staged_index(tx, ty, tz)
+        toff[c] = (unsigned)first * kTN + (unsigned)si;
+        moff[c] = (unsigned)first * 16u + (unsigned)(bit >> 5);
+        sh[c] = bit & 31;
+        nit[c] = n;
         maxc = max(maxc, n);
     }
-    // Eight rounds (items per candidate block) at a time.  Sparse tiles: first ALL mask words of these rounds (4 x 8 in flight,
-    // reduced to one bit each), then the tile loads that find something, RB rounds = 8 x RB loads in flight -- so a node covered
-    // by three items per block costs one round trip for the masks and ceil(3 / RB) for the tiles, not two per item.
-    // The order of the sum is (round, candidate) whatever RB: every instantiation returns the same bits.
-    // (Round 4 tried issuing the first round's tile loads TOGETHER with the mask loads and dropping unstored nodes afterwards --
-    // one dependent round trip fewer: 12.7 -> 15.5 us per launch at 1 M, the extra requests cost more than the trip saves;
-    // profiles/r4f_mpm_grid_speculative_tile_loads_rejected.txt.)
-    for (int r0 = 0; r0 < maxc; r0 += 8) {
-        unsigned long long live = ~0ull;     // bit r * 8 + c: the node is present in the tile of round r0 + r, candidate c
+    const unsigned* __restrict__ mask32 = reinterpret_cast<const unsigned*>(S.tile_mask);   // (little-endian halves of the 64-bit words)
+    const float4* __restrict__ part = S.part;
+    const unsigned zero = S.zero_off;
+    for (int r0 = 0; r0 < maxc; r0 += RB) {
+        unsigned idx[RB][8];
         if (S.sparse_tiles) {                // (uniform)
-            live = 0ull;
-            for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += 4) {
-                const unsigned* mask32 = reinterpret_cast<const unsigned*>(S.tile_mask);   // (little-endian halves of the 64-bit words)
-                unsigned w[4][8];
+            unsigned w[RB][8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int item = r0 + r1 + r;
-                        w[r][c] = (item < (cb[c] >> 16)) ? mask32[(size_t)((off[c] >> 9) + item) * 16 + ((cb[c] & 0xffff) >> 5)] : 0u;
-                    }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) live |= (unsigned long long)((w[r][c] >> (cb[c] & 31)) & 1u) << ((r1 + r) * 8 + c);
-            }
-        }
-        for (int r1 = 0; r1 < 8 && r0 + r1 < maxc; r1 += RB) {
-            float4 q[RB][8];
+                for (int c = 0; c < 8; ++c) w[r][c] = mask32[(r0 + r < nit[c]) ? moff[c] + (unsigned)(r0 + r) * 16u : 0u];
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const int item = r0 + r1 + r;
-                    const bool on = (item < (cb[c] >> 16)) && ((live >> ((r1 + r) * 8 + c)) & 1ull);
-                    q[r][c] = on ? S.part[off[c] + (unsigned)item * kTN] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const bool on = (r0 + r < nit[c]) && ((w[r][c] >> sh[c]) & 1u);
+                    idx[r][c] = on ? toff[c] + (unsigned)(r0 + r) * kTN : zero;
                 }
+        } else {
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
+                for (int c = 0; c < 8; ++c) idx[r][c] = (r0 + r < nit[c]) ? toff[c] + (unsigned)(r0 + r) * kTN : zero;
         }
+        float4 q[RB][8];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) q[r][c] = part[idx[r][c]];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { acc.x += q[r][c].x; acc.y += q[r][c].y; acc.z += q[r][c].z; acc.w += q[r][c].w; }
     }
     return acc;
 }
@@ -2019,7 +2044,7 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     rc |= dev_alloc(h, &blk_items, (size_t)nblocks, true); rc |= dev_alloc(h, &blk_flags, (size_t)nblocks, true);
     ScanTriple* scan_chunks = nullptr;
     rc |= dev_alloc(h, &scan_chunks, (size_t)cdiv(nblocks, kScanChunk), true);
-    rc |= dev_alloc(h, &part, max_items * kTN, true);
+    rc |= dev_alloc(h, &part, (max_items + 1) * kTN, true);     // (+ the zero tile of gather_node; dev_alloc clears, nothing ever writes it)
     rc |= dev_alloc(h, &tile_mask, max_items * 8, true);
     if (rc) {   // keep the old grid
         for (void* p : h->grid_allocs) (void)hipFree(p);
@@ -2036,6 +2061,7 @@ int alloc_grid(pixie_mpm* h, int n_grid, double grid_lim) {
     S.gin = gin; S.gout = gout;
     h->counts = counts; h->offsets = offsets; h->items = items; h->active_list = active_list; h->nbr_table = nbr_table;
     h->blk_items = blk_items; h->blk_flags = blk_flags; h->part = part; h->tile_mask = tile_mask;
+    S.zero_off = (unsigned)(max_items * kTN);
     h->scan_chunks = scan_chunks;
     h->n_items = 0; h->n_active = 0;
     h->auto_half_items = false;
