@@ -1287,9 +1287,16 @@ __device__ __forceinline__ float4 finish_node(const MpmPtrs& S, const StepParams
 template <int RB>
 __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepParams& sp, const BCSet& bcs, int slot, float4* dst) {
     const int lane = threadIdx.x & 63;
+#ifdef PIXIE_DIAG   // set_scalar "trace" 4: per active block four 100 MHz stamps -- start, neighbour row arrived, tiles summed, stored
+#define PX_GRID_STAMP(i) do { if ((sp.trace & 4) && lane == 0 && slot < kMpmTraceItems) { asm volatile("s_waitcnt vmcnt(0)"); g_mpm_trace[slot * 8 + (i)] = wall_clock64(); } } while (0)
+#else
+#define PX_GRID_STAMP(i) do { } while (0)
+#endif
+    PX_GRID_STAMP(0);
     // one coalesced row: block id + the work items of the 27 neighbours (lane q holds neighbour q)
     const int2 row = (lane < 28) ? S.nbr_table[(size_t)slot * 28 + lane] : make_int2(0, 0);
     const int blk = __shfl(row.x, 0);
+    PX_GRID_STAMP(1);
     int2 mine;
     mine.x = __shfl(row.x, (lane + 1) & 63); mine.y = __shfl(row.y, (lane + 1) & 63);
     const int Bz = blk % S.nbk, By = (blk / S.nbk) % S.nbk, Bx = blk / (S.nbk * S.nbk);
@@ -1300,6 +1307,7 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
     const bool inside = ix < S.ng && iy < S.ng && iz < S.ng;
     const size_t idx = ((size_t)ix * S.ng + iy) * S.ng + iz;
     float4 g = gather_node<RB>(S, mine, lx, ly, lz, make_float4(0.f, 0.f, 0.f, 0.f));   // does not wait for the flag
+    PX_GRID_STAMP(2);
     if (flag & 2) {
         if (inside) {
             const float4 q = S.gin[idx];
@@ -1308,8 +1316,12 @@ __device__ __forceinline__ void grid_block_update(const MpmPtrs& S, const StepPa
         }
         if (lane == 0) S.blk_flags[blk] = flag & 1;
     }
-    if (!inside) return;
-    dst[idx] = finish_node(S, sp, bcs, g, ix, iy, iz);
+    if (inside) dst[idx] = finish_node(S, sp, bcs, g, ix, iy, iz);
+    PX_GRID_STAMP(3);
+#ifdef PIXIE_DIAG
+    if ((sp.trace & 4) && lane == 0 && slot < kMpmTraceItems)
+        g_mpm_trace[slot * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+#endif
 }
 
 // One wave per 4x4x4 block of nodes.  A block is ACTIVE when one of its 27 neighbours (itself included) holds particles.
@@ -1897,7 +1909,7 @@ void launch_fused_block(const pixie_mpm* h, hipStream_t st, const StepParams& sp
     // once): up to that many the whole work list is resident in one round and a launch lasts one work item's latency.
     const bool wide = h->wide == 1 || (h->wide < 0 && h->n_items <= 3 * h->n_cus);
 #ifdef PIXIE_DIAG
-    if (h->trace) { launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms); return; }
+    if (h->trace & ~4) { launch_block_p<true, true, 5, F_TRACE>(h, pack, grid, st, sp, pms); return; }
 #endif
     if (wide) launch_block_p<true, true, 2, F_WIDE>(h, pack, grid, st, sp, pms);
     else if (h->occupancy >= 6 && !pack) launch_block<true, true, 6, 0>(h, grid, st, sp, pms);   // six waves per SIMD: the exact scatter only (the one measured and tested)
